@@ -1,0 +1,127 @@
+"""The CPU oracle (oracle/rt_oracle.c) against images the reference shader produced on llvmpipe.
+
+Every comparison here is bit-for-bit.  The golden data under tests/golden/ was written by
+oracle/gen_fixtures.py, which executes the reference's own shaders/compute.glsl.
+"""
+
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _cases(golden):
+    out = []
+    for sdir in sorted(p for p in golden.iterdir() if p.is_dir()):
+        for j in sorted(sdir.glob("*.json")):
+            if j.name == "meta.json" or j.name.endswith(".state.json"):
+                continue
+            out.append((sdir.name, j.stem))
+    return out
+
+
+from conftest import GOLDEN  # noqa: E402
+
+CASES = _cases(GOLDEN)
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = O.OracleScene.from_dir(GOLDEN / name)
+        return cache[name]
+
+    return get
+
+
+@pytest.mark.parametrize("scene,tag", CASES)
+def test_colour_frames_bit_exact(scenes, scene, tag):
+    rec = json.loads((GOLDEN / scene / f"{tag}.json").read_text())
+    w, h, b = rec["w"], rec["h"], rec["bounces"]
+    f0, f1 = rec["frames"]
+    hashes = rec["kinds"]["color"]["sha256_per_frame"] if "kinds" in rec else rec["sha256_per_frame"]
+    if w * h * (f1 - f0) > 640 * 360 * 8:
+        f1 = f0 + 1 if w > 1000 else f0 + 16  # keep the CPU suite short; the GPU suite checks them all
+    sc = scenes(scene)
+    for i, f in enumerate(range(f0, f1)):
+        img = sc.render(w, h, f, b)
+        assert sha(img) == hashes[i], f"{scene}/{tag} frame {f}"
+
+
+@pytest.mark.parametrize("scene,tag", [c for c in CASES if (GOLDEN / c[0] / f"{c[1]}.primary.npy").exists()])
+def test_primary_hits_bit_exact(scenes, scene, tag):
+    rec = json.loads((GOLDEN / scene / f"{tag}.json").read_text())
+    g = np.load(GOLDEN / scene / f"{tag}.primary.npy")
+    w, h, b = rec["w"], rec["h"], rec["bounces"]
+    f0, f1 = rec["frames"]
+    sc = scenes(scene)
+    for i, f in enumerate(range(f0, f1)):
+        _, aux = sc.render(w, h, f, b, want_primary=True)
+        code, tbits, exists = O.primary_from_golden(g[i])
+        assert np.array_equal(code, aux[..., 0])
+        assert np.array_equal(tbits, aux[..., 1])
+        assert np.array_equal(exists, aux[..., 2])
+
+
+@pytest.mark.parametrize("scene,tag", [(p.parent.name, p.name[: -len(".state.npz")])
+                                       for p in sorted(GOLDEN.glob("*/*.state.npz"))])
+def test_per_bounce_state_bit_exact(scenes, scene, tag):
+    """Ray direction, origin and throughput after bounces 0..2, as witnessed through the alpha channel."""
+    meta = json.loads((GOLDEN / scene / f"{tag}.state.json").read_text())
+    z = np.load(GOLDEN / scene / f"{tag}.state.npz")
+    w, h, frame = meta["w"], meta["h"], meta["frame"]
+    sc = scenes(scene)
+    slot = {"dx": 4, "dy": 5, "dz": 6, "ox": 7, "oy": 8, "oz": 9, "thr_x": 10}
+    for bnc in meta["capture_bounces"]:
+        # rendering with bounces = bnc+1 leaves the state of bounce `bnc` in the aux record
+        _, aux = sc.render(w, h, frame, bnc + 1, want_primary=True)
+        # pixels that finished bounce `bnc`: the capture is non-zero in at least one direction component
+        reached = (z[f"b{bnc}_dx"] != 0) | (z[f"b{bnc}_dy"] != 0) | (z[f"b{bnc}_dz"] != 0)
+        assert reached.sum() > 1000
+        for key, idx in slot.items():
+            if key == "thr_x" and bnc >= 3:
+                continue
+            ref = z[f"b{bnc}_{key}"].view(np.uint32)
+            assert np.array_equal(ref[reached], aux[..., idx][reached]), f"bounce {bnc} {key}"
+
+
+def test_counters_close_to_instrumented_shader(scenes):
+    """Work counters come from a differently compiled (instrumented) shader whose inexact
+    optimisations differ in rare pixels, so they are compared with a small tolerance."""
+    rec = json.loads((GOLDEN / "gally" / "mid_640x360_b4.json").read_text())
+    c = rec["kinds"]["counters"]
+    tot = {"rays": 0, "nodes": 0, "tri_tests": 0, "sphere_tests": 0}
+    sc = scenes("gally")
+    f0, f1 = rec["frames"]
+    mx = 0
+    for f in range(f0, f1):
+        _, cnt = sc.render(rec["w"], rec["h"], f, rec["bounces"], want_counters=True)
+        for k in tot:
+            tot[k] += cnt[k]
+        mx = max(mx, cnt["max_stack"])
+    assert tot["rays"] == c["rays"]
+    for k in ("nodes", "tri_tests", "sphere_tests"):
+        assert abs(tot[k] - c[k]) <= 1e-4 * c[k]
+    assert mx == c["max_stack"]
+
+
+def test_known_answers():
+    L = O.lib()
+    # exp2/log2/pow edge behaviour of the polynomial forms
+    assert L.rto_exp2(-127.0) == 0.0
+    assert L.rto_exp2(128.0) == float("inf")
+    assert L.rto_log2(0.0) == float("-inf")
+    assert L.rto_pow(0.0, 5.0) == 0.0
+    assert L.rto_pow(1.0, 2.4) == 1.0
+    assert abs(L.rto_sin(1.0) - np.sin(1.0)) < 2e-7
+    assert abs(L.rto_cos(5.0) - np.cos(5.0)) < 2e-7
