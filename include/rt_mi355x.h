@@ -1,0 +1,132 @@
+/*
+ * rt_mi355x.h — C ABI of librt_mi355x.so, the MI355X (gfx950) implementation of the path
+ * tracer's per-frame compute dispatch.
+ *
+ * Each entry point cites the piece of the reference renderer it stands in for
+ * (paths relative to the reference repository).  All functions return 0 on success and a
+ * non-zero code on failure; rt_last_error() then describes the failure.  A context is bound
+ * to one GPU and is not thread-safe; use one context per device.
+ *
+ * Buffer layouts are the reference's std430 layouts, byte for byte:
+ *   binding  5  spheres   32 B/elem   (shaders/compute.glsl:14-19,  src/primitive/sphere/sphere.py:38-51)
+ *   binding  6  planes    32 B/elem   (compute.glsl:22-26,          src/primitive/plane/plane.py:37-45)
+ *   binding  7  boxes     32 B/elem   (compute.glsl:37-41,          src/primitive/box/box.py:39-47)
+ *   binding  9  materials 12 B/elem   (compute.glsl:43-47,          src/material/material.py:48-55)
+ *   binding 11  BVH nodes 64 B/elem   (compute.glsl:6-11,           src/bvh/bvh_node.py:337-344)
+ *   binding 12  triangles 64 B/elem   (compute.glsl:29-35,          src/primitive/triangle/triangle.py:48-55)
+ * Images are RGBA32F, row 0 = bottom row (the GL image convention the shader writes in).
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+enum {
+    RT_BINDING_SPHERES = 5,
+    RT_BINDING_PLANES = 6,
+    RT_BINDING_BOXES = 7,
+    RT_BINDING_MATERIALS = 9,
+    RT_BINDING_BVH = 11,
+    RT_BINDING_TRIANGLES = 12
+};
+
+/* rt_render flags */
+enum {
+    RT_FLAG_AUX = 1u,        /* also record the 16-word per-pixel parity record (rt_read_aux)   */
+    RT_FLAG_STATS = 2u,      /* also count node visits and primitive tests (slower)              */
+    RT_FLAG_NO_SAMPLE = 4u   /* do not store the per-frame sample image, only the accumulation   */
+};
+
+typedef struct {
+    uint64_t rays;          /* traverse calls (one per loop iteration of compute.glsl:498-500)   */
+    uint64_t pixel_samples; /* pixel-samples rendered                                            */
+    uint64_t nodes;         /* node visits           (RT_FLAG_STATS only)                        */
+    uint64_t tri_tests;     /* triangle tests        (RT_FLAG_STATS only)                        */
+    uint64_t sphere_tests;  /* sphere tests          (RT_FLAG_STATS only)                        */
+    uint64_t box_tests;     /* box tests             (RT_FLAG_STATS only)                        */
+    uint64_t max_stack;     /* deepest traversal stack seen (RT_FLAG_STATS only)                 */
+    uint64_t stack_overflows; /* pushes dropped because the stack was full (always counted)      */
+    double last_render_ms;  /* device time of the last rt_render / rt_render_sum call            */
+    double last_trace_ms;   /* device time spent in the trace kernel(s) of that call             */
+} rt_stats;
+
+/* Stands in for Renderer.__init__ (src/renderer/renderer.py:64-154): creates the device
+ * objects.  `device` is the HIP device ordinal.  Default size 1280x720 (renderer.py:75-76). */
+int rt_create(int device, rt_ctx **out);
+int rt_destroy(rt_ctx *ctx);
+
+/* Message for the most recent failure on the calling thread. */
+const char *rt_last_error(void);
+
+/* Renderer.update_size (renderer.py:347-382): reallocates the three images, contents zeroed. */
+int rt_resize(rt_ctx *ctx, int width, int height);
+
+/* Renderer.update_ssbo (renderer.py:308-324): copies `nbytes` of host data into the buffer
+ * for `binding`, replacing it wholesale.  The caller keeps ownership of `data`. */
+int rt_upload(rt_ctx *ctx, int binding, const void *data, size_t nbytes);
+
+/* renderer.scene_min_coords / renderer.scene_extent (src/scene/scene.py:70-71), sent as the
+ * uniforms scene_min / scene_extent (renderer.py:199-210). */
+int rt_set_scene_bounds(rt_ctx *ctx, const float scene_min[3], const float scene_extent[3]);
+
+/* Uniforms inverse_view_projection (16 floats in memory order, sent untransposed) and eye
+ * (renderer.py:186-198). */
+int rt_set_camera(rt_ctx *ctx, const float inv_view_proj[16], const float eye[3]);
+
+/* One Renderer.render() per frame (renderer.py:164-306), `nframes` times: the compute dispatch
+ * with time = first_frame + i and the given `bounces` uniform (renderer.py:211-246), then the
+ * accumulate pass (shaders/screen_fragment.glsl:94-108, renderer.py:249-288) which folds the
+ * sample into the running mean and increments the accumulated-frame count.  Asynchronous;
+ * rt_sync or any rt_read_* waits for it. */
+int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t nframes, float bounces, uint32_t flags);
+
+/* Renderer.reset_accumulation (renderer.py:326-345): the accumulation image becomes a copy of the
+ * last sample image and the accumulated-frame count returns to 0. */
+int rt_reset_accumulation(rt_ctx *ctx);
+
+/* Number of frames folded into the accumulation image (Renderer.rendered_frames). */
+int rt_rendered_frames(rt_ctx *ctx, uint32_t *out);
+
+/* The image the compute shader stores (compute.glsl:673): sRGB-encoded sample of the last frame. */
+int rt_read_sample(rt_ctx *ctx, float *rgba);
+/* The accumulation image (`_last_frame` / `_color_tex`, renderer.py:274-286), sRGB-encoded. */
+int rt_read_accumulation(rt_ctx *ctx, float *rgba);
+/* Parity record of the last frame rendered with RT_FLAG_AUX: 16 u32 per pixel,
+ *   [0] type<<30|index of the primitive the first ray hit (0xFFFFFFFF: none), [1] bits of that
+ *   ray's hit distance, [2] hit exists, [3] node visits (RT_FLAG_STATS), [4..6] ray direction,
+ *   [7..9] ray origin, [10..12] throughput, [13] RNG state, [14] rays traced, [15] ray ior —
+ *   [4..15] as they stand when the bounce loop ends. */
+int rt_read_aux(rt_ctx *ctx, uint32_t *aux16);
+
+int rt_get_stats(rt_ctx *ctx, rt_stats *out);
+int rt_reset_stats(rt_ctx *ctx);
+int rt_sync(rt_ctx *ctx);
+
+/*
+ * Sharded rendering for multi-GPU runs (no counterpart in the reference, which renders every
+ * pixel of every frame on one device).  Renders frames [first_frame, first_frame+nframes) for the
+ * image tiles owned by shard `shard` of `nshards` (tiles of 64x64 pixels dealt round-robin in
+ * Morton order) and ADDS each sample's linear radiance into `sum_rgba` (device pointer, W*H*4 f32,
+ * caller-zeroed; NULL selects the context's own buffer).  Frames may also be strided:
+ * only frames f with (f - first_frame) % frame_stride == frame_phase are rendered.
+ * After the per-GPU buffers are summed (RCCL reduce), rt_finalize_sum turns the sum into the
+ * sRGB-encoded mean image.
+ */
+int rt_render_sum(rt_ctx *ctx, uint32_t first_frame, uint32_t nframes, float bounces, uint32_t shard,
+                  uint32_t nshards, uint32_t frame_stride, uint32_t frame_phase, float *sum_rgba);
+int rt_sum_buffer(rt_ctx *ctx, float **device_ptr, size_t *nbytes);
+int rt_clear_sum(rt_ctx *ctx, float *sum_rgba);
+/* accumulation image = srgb(sum / spp), alpha 1 */
+int rt_finalize_sum(rt_ctx *ctx, const float *sum_rgba, uint32_t spp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

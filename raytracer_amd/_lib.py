@@ -1,0 +1,80 @@
+"""ctypes binding of librt_mi355x.so (the C ABI declared in include/rt_mi355x.h).
+
+There is no fallback: if the library is missing or no HIP device is usable, the calls raise.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "librt_mi355x.so"
+
+# every symbol include/rt_mi355x.h declares
+SYMBOLS = (
+    "rt_create", "rt_destroy", "rt_last_error", "rt_resize", "rt_upload", "rt_set_scene_bounds", "rt_set_camera",
+    "rt_render", "rt_reset_accumulation", "rt_rendered_frames", "rt_read_sample", "rt_read_accumulation",
+    "rt_read_aux", "rt_get_stats", "rt_reset_stats", "rt_sync", "rt_render_sum", "rt_sum_buffer", "rt_clear_sum",
+    "rt_finalize_sum",
+)
+
+RT_FLAG_AUX = 1
+RT_FLAG_STATS = 2
+RT_FLAG_NO_SAMPLE = 4
+
+
+class RtStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "pixel_samples", "nodes", "tri_tests", "sphere_tests", "box_tests",
+                                           "max_stack", "stack_overflows")] + [("last_render_ms", C.c_double),
+                                                                               ("last_trace_ms", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` (hipcc, gfx950). "
+            "There is no CPU fallback for the render path."
+        )
+    L = C.CDLL(str(LIB_PATH))
+    vp = C.c_void_p
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_last_error.argtypes = []
+    sig = {
+        "rt_create": [C.c_int, C.POINTER(vp)],
+        "rt_destroy": [vp],
+        "rt_resize": [vp, C.c_int, C.c_int],
+        "rt_upload": [vp, C.c_int, vp, C.c_size_t],
+        "rt_set_scene_bounds": [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)],
+        "rt_set_camera": [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)],
+        "rt_render": [vp, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32],
+        "rt_reset_accumulation": [vp],
+        "rt_rendered_frames": [vp, C.POINTER(C.c_uint32)],
+        "rt_read_sample": [vp, vp],
+        "rt_read_accumulation": [vp, vp],
+        "rt_read_aux": [vp, vp],
+        "rt_get_stats": [vp, C.POINTER(RtStats)],
+        "rt_reset_stats": [vp],
+        "rt_sync": [vp],
+        "rt_render_sum": [vp, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp],
+        "rt_sum_buffer": [vp, C.POINTER(vp), C.POINTER(C.c_size_t)],
+        "rt_clear_sum": [vp, vp],
+        "rt_finalize_sum": [vp, vp, C.c_uint32],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.restype = C.c_int
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(load().rt_last_error().decode(errors="replace"))

@@ -1,0 +1,438 @@
+// C ABI of librt_mi355x.so (see include/rt_mi355x.h).  Host-side state and launch logic only;
+// all device code is in rt_kernels.hip.  There is no CPU fallback: every entry point needs a
+// working HIP device and reports a HIP failure as an error.
+
+#include "../../include/rt_mi355x.h"
+#include "rt_internal.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string &m) {
+    g_err = m;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                            \
+    } while (0)
+
+struct RawBuffer {           // device copy of an uploaded reference-layout buffer
+    uint32_t *raw = nullptr;  // as uploaded
+    size_t raw_bytes = 0;
+    uint32_t count = 0;       // elements
+    float4 *packed = nullptr; // device records (count + 1 elements)
+    size_t packed_cap = 0;    // capacity in float4
+    bool dirty = true;        // packed is stale
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int W = 1280, H = 720;
+    RawBuffer spheres, planes, boxes, mats, nodes, tris;
+    float smin[3] = {0, 0, 0}, sext[3] = {0, 0, 0};
+    float inv_vp[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    float eye[3] = {0, 0, 0};
+    float4 *sample = nullptr, *acc = nullptr, *sum = nullptr;
+    uint32_t *aux = nullptr;
+    rt::Counters *counters = nullptr;
+    uint32_t rendered_frames = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> ev_trace;  // pairs around trace kernels of the last call
+    size_t ev_trace_used = 0;
+    bool timed = false;
+};
+
+namespace {
+
+int stride_of(int binding) {
+    switch (binding) {
+        case RT_BINDING_SPHERES:
+        case RT_BINDING_PLANES:
+        case RT_BINDING_BOXES: return 32;
+        case RT_BINDING_MATERIALS: return 12;
+        case RT_BINDING_BVH:
+        case RT_BINDING_TRIANGLES: return 64;
+        default: return 0;
+    }
+}
+
+RawBuffer *buffer_of(rt_ctx *c, int binding) {
+    switch (binding) {
+        case RT_BINDING_SPHERES: return &c->spheres;
+        case RT_BINDING_PLANES: return &c->planes;
+        case RT_BINDING_BOXES: return &c->boxes;
+        case RT_BINDING_MATERIALS: return &c->mats;
+        case RT_BINDING_BVH: return &c->nodes;
+        case RT_BINDING_TRIANGLES: return &c->tris;
+        default: return nullptr;
+    }
+}
+
+int vecs_per_elem(int binding) {
+    switch (binding) {
+        case RT_BINDING_BVH: return rt::kNodeVec;
+        case RT_BINDING_TRIANGLES: return rt::kTriVec;
+        case RT_BINDING_MATERIALS: return rt::kMatVec;
+        default: return 2;
+    }
+}
+
+int alloc_images(rt_ctx *c) {
+    size_t n = (size_t)c->W * c->H;
+    for (float4 **p : {&c->sample, &c->acc, &c->sum}) {
+        if (*p) HIP_TRY(hipFree(*p));
+        *p = nullptr;
+        HIP_TRY(hipMalloc((void **)p, n * sizeof(float4)));
+        HIP_TRY(hipMemsetAsync(*p, 0, n * sizeof(float4), c->stream));
+    }
+    if (c->aux) {
+        HIP_TRY(hipFree(c->aux));
+        c->aux = nullptr;
+    }
+    c->rendered_frames = 0;
+    return 0;
+}
+
+// brings the device records of one binding up to date
+int repack(rt_ctx *c, int binding) {
+    RawBuffer *b = buffer_of(c, binding);
+    if (!b->dirty) return 0;
+    size_t need = ((size_t)b->count + 1) * vecs_per_elem(binding);
+    if (need > b->packed_cap) {
+        if (b->packed) HIP_TRY(hipFree(b->packed));
+        b->packed = nullptr;
+        HIP_TRY(hipMalloc((void **)&b->packed, need * sizeof(float4)));
+        b->packed_cap = need;
+    }
+    switch (binding) {
+        case RT_BINDING_BVH: rt::launch_repack_nodes(b->raw, b->count, c->smin, c->sext, b->packed, c->stream); break;
+        case RT_BINDING_TRIANGLES: rt::launch_repack_tris(b->raw, b->count, b->packed, c->stream); break;
+        case RT_BINDING_SPHERES: rt::launch_repack_spheres(b->raw, b->count, b->packed, c->stream); break;
+        case RT_BINDING_MATERIALS: rt::launch_repack_mats(b->raw, b->count, b->packed, c->stream); break;
+        default: rt::launch_copy_raw32(b->raw, b->count, b->packed, c->stream); break;
+    }
+    HIP_TRY(hipGetLastError());
+    b->dirty = false;
+    return 0;
+}
+
+int prepare_scene(rt_ctx *c, rt::DevScene *s) {
+    for (int binding : {RT_BINDING_SPHERES, RT_BINDING_PLANES, RT_BINDING_BOXES, RT_BINDING_MATERIALS,
+                        RT_BINDING_BVH, RT_BINDING_TRIANGLES})
+        if (int rc = repack(c, binding)) return rc;
+    s->nodes = c->nodes.packed;
+    s->tris = c->tris.packed;
+    s->spheres = c->spheres.packed;
+    s->boxes = c->boxes.packed;
+    s->planes = c->planes.packed;
+    s->mats = c->mats.packed;
+    s->n_nodes = c->nodes.count;
+    s->n_tris = c->tris.count;
+    s->n_spheres = c->spheres.count;
+    s->n_boxes = c->boxes.count;
+    s->n_planes = c->planes.count;
+    s->n_mats = c->mats.count;
+    memcpy(s->inv_vp, c->inv_vp, sizeof s->inv_vp);
+    memcpy(s->eye, c->eye, sizeof s->eye);
+    return 0;
+}
+
+void fill_params(rt_ctx *c, rt::TraceParams *p) {
+    p->W = c->W;
+    p->H = c->H;
+    p->WW = (c->W / 8) * 8;  // glDispatchCompute(int(W/8), int(H/4), 1) with 8x4 groups
+    p->HH = (c->H / 4) * 4;
+    p->sample = c->sample;
+    p->sum = c->sum;
+    p->aux = nullptr;
+    p->counters = c->counters;
+    p->shard = 0;
+    p->nshards = 1;
+    p->tiles_x = (uint32_t)((p->WW + 15) / 16);
+    p->tiles_y = (uint32_t)((p->HH + 15) / 16);
+    p->ntiles = p->tiles_x * p->tiles_y;
+}
+
+int begin_timed(rt_ctx *c) {
+    HIP_TRY(hipEventRecord(c->ev_begin, c->stream));
+    c->ev_trace_used = 0;
+    return 0;
+}
+
+int trace_event(rt_ctx *c) {  // records the next event of the pool on the stream
+    if (c->ev_trace_used >= c->ev_trace.size()) {
+        if (c->ev_trace.size() >= 512) return 0;  // long runs: only the first 256 frames are split out
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        c->ev_trace.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(c->ev_trace[c->ev_trace_used++], c->stream));
+    return 0;
+}
+
+int end_timed(rt_ctx *c) {
+    HIP_TRY(hipEventRecord(c->ev_end, c->stream));
+    c->timed = true;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_err.c_str(); }
+
+int rt_create(int device, rt_ctx **out) {
+    if (!out) return fail("rt_create: out is null");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("rt_create: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    rt_ctx *c = new rt_ctx();
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->ev_begin));
+    HIP_TRY(hipEventCreate(&c->ev_end));
+    HIP_TRY(hipMalloc((void **)&c->counters, sizeof(rt::Counters)));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(rt::Counters), c->stream));
+    if (int rc = alloc_images(c)) return rc;
+    *out = c;
+    return 0;
+}
+
+int rt_destroy(rt_ctx *c) {
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (RawBuffer *b : {&c->spheres, &c->planes, &c->boxes, &c->mats, &c->nodes, &c->tris}) {
+        if (b->raw) hipFree(b->raw);
+        if (b->packed) hipFree(b->packed);
+    }
+    for (void *p : {(void *)c->sample, (void *)c->acc, (void *)c->sum, (void *)c->aux, (void *)c->counters})
+        if (p) hipFree(p);
+    for (hipEvent_t e : c->ev_trace) hipEventDestroy(e);
+    hipEventDestroy(c->ev_begin);
+    hipEventDestroy(c->ev_end);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int rt_resize(rt_ctx *c, int width, int height) {
+    if (!c) return fail("rt_resize: null context");
+    if (width <= 0 || height <= 0) return fail("rt_resize: size must be positive");
+    if ((size_t)width * (size_t)height > ((size_t)1 << 28)) return fail("rt_resize: image too large");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->W = width;
+    c->H = height;
+    return alloc_images(c);
+}
+
+int rt_upload(rt_ctx *c, int binding, const void *data, size_t nbytes) {
+    if (!c) return fail("rt_upload: null context");
+    RawBuffer *b = buffer_of(c, binding);
+    if (!b) return fail("rt_upload: unknown binding " + std::to_string(binding));
+    if (nbytes && !data) return fail("rt_upload: null data");
+    int stride = stride_of(binding);
+    if (nbytes % (size_t)stride) return fail("rt_upload: size is not a multiple of the element stride");
+    if (nbytes / (size_t)stride >= ((size_t)1 << 30)) return fail("rt_upload: too many elements");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the old buffer may still be in use
+    if (b->raw) HIP_TRY(hipFree(b->raw));
+    b->raw = nullptr;
+    b->raw_bytes = nbytes;
+    b->count = (uint32_t)(nbytes / (size_t)stride);
+    if (nbytes) {
+        HIP_TRY(hipMalloc((void **)&b->raw, nbytes));
+        // the caller's array may be reused as soon as this returns, as with glBufferData
+        HIP_TRY(hipMemcpy(b->raw, data, nbytes, hipMemcpyHostToDevice));
+    }
+    b->dirty = true;
+    return 0;
+}
+
+int rt_set_scene_bounds(rt_ctx *c, const float mn[3], const float ext[3]) {
+    if (!c || !mn || !ext) return fail("rt_set_scene_bounds: null argument");
+    if (memcmp(c->smin, mn, 12) || memcmp(c->sext, ext, 12)) c->nodes.dirty = true;  // boxes are decoded with them
+    memcpy(c->smin, mn, 12);
+    memcpy(c->sext, ext, 12);
+    return 0;
+}
+
+int rt_set_camera(rt_ctx *c, const float m[16], const float eye[3]) {
+    if (!c || !m || !eye) return fail("rt_set_camera: null argument");
+    memcpy(c->inv_vp, m, 64);
+    memcpy(c->eye, eye, 12);
+    return 0;
+}
+
+int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounces, uint32_t flags) {
+    if (!c) return fail("rt_render: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    rt::TraceParams p;
+    if (int rc = prepare_scene(c, &p.scene)) return rc;
+    fill_params(c, &p);
+    size_t npix = (size_t)c->W * c->H;
+    const bool aux = flags & RT_FLAG_AUX, stats = flags & RT_FLAG_STATS;
+    if (aux && !c->aux) {
+        HIP_TRY(hipMalloc((void **)&c->aux, npix * 16 * sizeof(uint32_t)));
+    }
+    if (aux) HIP_TRY(hipMemsetAsync(c->aux, 0, npix * 16 * sizeof(uint32_t), c->stream));
+    p.aux = aux ? c->aux : nullptr;
+    p.bounces = bounces;
+    if (int rc = begin_timed(c)) return rc;
+    for (uint32_t i = 0; i < nframes; i++) {
+        p.time = (float)(first_frame + i);  // renderer.py:211 float(self._frames)
+        if (int rc = trace_event(c)) return rc;
+        rt::launch_trace(p, 0, aux, stats, c->stream);
+        if (int rc = trace_event(c)) return rc;
+        rt::launch_accumulate(c->sample, c->acc, npix, (float)c->rendered_frames, c->stream);
+        c->rendered_frames++;
+    }
+    HIP_TRY(hipGetLastError());
+    return end_timed(c);
+}
+
+int rt_reset_accumulation(rt_ctx *c) {
+    if (!c) return fail("rt_reset_accumulation: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->acc, c->sample, (size_t)c->W * c->H * sizeof(float4), hipMemcpyDeviceToDevice,
+                           c->stream));
+    c->rendered_frames = 0;
+    return 0;
+}
+
+int rt_rendered_frames(rt_ctx *c, uint32_t *out) {
+    if (!c || !out) return fail("rt_rendered_frames: null argument");
+    *out = c->rendered_frames;
+    return 0;
+}
+
+static int read_image(rt_ctx *c, const void *dev, void *host, size_t bytes, const char *what) {
+    if (!c || !host) return fail(std::string(what) + ": null argument");
+    if (!dev) return fail(std::string(what) + ": nothing has been rendered into that buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rt_read_sample(rt_ctx *c, float *rgba) {
+    return read_image(c, c ? c->sample : nullptr, rgba, c ? (size_t)c->W * c->H * 16 : 0, "rt_read_sample");
+}
+int rt_read_accumulation(rt_ctx *c, float *rgba) {
+    return read_image(c, c ? c->acc : nullptr, rgba, c ? (size_t)c->W * c->H * 16 : 0, "rt_read_accumulation");
+}
+int rt_read_aux(rt_ctx *c, uint32_t *aux16) {
+    return read_image(c, c ? c->aux : nullptr, aux16, c ? (size_t)c->W * c->H * 64 : 0, "rt_read_aux");
+}
+
+int rt_sync(rt_ctx *c) {
+    if (!c) return fail("rt_sync: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rt_get_stats(rt_ctx *c, rt_stats *out) {
+    if (!c || !out) return fail("rt_get_stats: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    rt::Counters h;
+    HIP_TRY(hipMemcpyAsync(&h, c->counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    out->rays = h.rays;
+    out->pixel_samples = h.pixel_samples;
+    out->nodes = h.nodes;
+    out->tri_tests = h.tri_tests;
+    out->sphere_tests = h.sphere_tests;
+    out->box_tests = h.box_tests;
+    out->max_stack = h.max_stack;
+    out->stack_overflows = h.stack_overflows;
+    out->last_render_ms = 0.0;
+    out->last_trace_ms = 0.0;
+    if (c->timed) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
+        out->last_render_ms = ms;
+        double t = 0.0;
+        for (size_t i = 0; i + 1 < c->ev_trace_used; i += 2) {
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev_trace[i], c->ev_trace[i + 1]));
+            t += ms;
+        }
+        out->last_trace_ms = t;
+    }
+    return 0;
+}
+
+int rt_reset_stats(rt_ctx *c) {
+    if (!c) return fail("rt_reset_stats: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(rt::Counters), c->stream));
+    return 0;
+}
+
+int rt_render_sum(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounces, uint32_t shard,
+                  uint32_t nshards, uint32_t frame_stride, uint32_t frame_phase, float *sum_rgba) {
+    if (!c) return fail("rt_render_sum: null context");
+    if (nshards == 0 || shard >= nshards) return fail("rt_render_sum: shard must be < nshards");
+    if (frame_stride == 0 || frame_phase >= frame_stride) return fail("rt_render_sum: frame_phase must be < frame_stride");
+    HIP_TRY(hipSetDevice(c->device));
+    rt::TraceParams p;
+    if (int rc = prepare_scene(c, &p.scene)) return rc;
+    fill_params(c, &p);
+    p.sample = nullptr;
+    p.sum = sum_rgba ? reinterpret_cast<float4 *>(sum_rgba) : c->sum;
+    p.shard = shard;
+    p.nshards = nshards;
+    p.bounces = bounces;
+    if (int rc = begin_timed(c)) return rc;
+    for (uint32_t i = frame_phase; i < nframes; i += frame_stride) {
+        p.time = (float)(first_frame + i);
+        if (int rc = trace_event(c)) return rc;
+        rt::launch_trace(p, 1, false, false, c->stream);
+        if (int rc = trace_event(c)) return rc;
+    }
+    HIP_TRY(hipGetLastError());
+    return end_timed(c);
+}
+
+int rt_sum_buffer(rt_ctx *c, float **device_ptr, size_t *nbytes) {
+    if (!c || !device_ptr || !nbytes) return fail("rt_sum_buffer: null argument");
+    *device_ptr = reinterpret_cast<float *>(c->sum);
+    *nbytes = (size_t)c->W * c->H * sizeof(float4);
+    return 0;
+}
+
+int rt_clear_sum(rt_ctx *c, float *sum_rgba) {
+    if (!c) return fail("rt_clear_sum: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(sum_rgba ? (void *)sum_rgba : (void *)c->sum, 0, (size_t)c->W * c->H * sizeof(float4),
+                           c->stream));
+    return 0;
+}
+
+int rt_finalize_sum(rt_ctx *c, const float *sum_rgba, uint32_t spp) {
+    if (!c) return fail("rt_finalize_sum: null context");
+    if (spp == 0) return fail("rt_finalize_sum: spp must be positive");
+    HIP_TRY(hipSetDevice(c->device));
+    rt::launch_finalize_sum(sum_rgba ? reinterpret_cast<const float4 *>(sum_rgba) : c->sum, c->acc,
+                            (size_t)c->W * c->H, spp, c->stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

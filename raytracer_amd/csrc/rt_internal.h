@@ -1,0 +1,73 @@
+// Internal interface between the C ABI (rt_api.cpp) and the device code (rt_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+// ---- device-side record layouts (what the repack kernels produce) -------------------------
+// Node: 128 B = 8 x float4, one L2 cache line, child boxes already decoded to fp32:
+//   [0] min_x[4] [1] max_x[4] [2] min_y[4] [3] max_y[4] [4] min_z[4] [5] max_z[4]
+//   [6] metadata[4] (bit pattern, type<<30 | index)   [7] unused
+// Triangle: 64 B = 4 x float4:
+//   [0] v0.xyz, material   [1] e1.xyz, n.x   [2] e2.xyz, n.y   [3] n.z, 0, 0, 0
+// Sphere: 32 B = 2 x float4:   [0] centre.xyz, radius^2   [1] material, 0, 0, 0
+// Material: 64 B = 4 x float4:
+//   [0] emitted.rgb (emission*strength), smoothness   [1] specular tint.rgb, transmission
+//   [2] diffuse albedo.rgb (colour*(1-metallic)), f0  [3] ior, ggx a2, metallic, 0
+// Boxes and planes keep the reference layout (2 x float4 each).
+constexpr int kNodeVec = 8;
+constexpr int kTriVec = 4;
+constexpr int kSphereVec = 2;
+constexpr int kMatVec = 4;
+
+struct DevScene {
+    const float4 *nodes;
+    const float4 *tris;
+    const float4 *spheres;
+    const float4 *boxes;
+    const float4 *planes;
+    const float4 *mats;
+    // element counts; every repacked array carries one extra all-zero-source element at index n,
+    // which is what an out-of-range index reads (GL robust buffer access returns zeros)
+    uint32_t n_nodes, n_tris, n_spheres, n_boxes, n_planes, n_mats;
+    float inv_vp[16];
+    float eye[3];
+};
+
+struct Counters {  // lives in device memory, 16 x u64
+    unsigned long long rays, pixel_samples, nodes, tri_tests, sphere_tests, box_tests, max_stack, stack_overflows;
+    unsigned long long pad[8];
+};
+
+struct TraceParams {
+    DevScene scene;
+    int W, H;            // image size
+    int WW, HH;          // pixels the reference dispatch covers: 8*(W/8) x 4*(H/4)
+    float time;          // the `time` uniform (frame index)
+    float bounces;       // the `bounces` uniform
+    float4 *sample;      // mode 0: sRGB-encoded sample image (may be null)
+    float4 *sum;         // mode 1: linear radiance sum image
+    uint32_t *aux;       // 16 words per pixel or null
+    Counters *counters;
+    uint32_t shard, nshards;  // mode 1 tile ownership
+    uint32_t tiles_x, tiles_y, ntiles;  // 16x16 pixel tiles
+};
+
+// repack kernels: reference byte layouts -> device records (n elements + 1 zero-source sentinel)
+void launch_repack_nodes(const uint32_t *src, uint32_t n, const float smin[3], const float sext[3], float4 *dst,
+                         hipStream_t s);
+void launch_repack_tris(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s);
+void launch_repack_spheres(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s);
+void launch_repack_mats(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s);
+void launch_copy_raw32(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s);  // boxes/planes + sentinel
+
+// mode 0 = reference frame (writes sample), mode 1 = add linear radiance into sum
+void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s);
+// accumulate pass: acc = srgb(lin(acc) + (lin(sample) - lin(acc)) / (frames + 1))
+void launch_accumulate(const float4 *sample, float4 *acc, size_t npixels, float frames, hipStream_t s);
+// acc = srgb(sum / spp)
+void launch_finalize_sum(const float4 *sum, float4 *acc, size_t npixels, uint32_t spp, hipStream_t s);
+
+}  // namespace rt

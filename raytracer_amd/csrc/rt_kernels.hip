@@ -1,0 +1,748 @@
+// Device code for gfx950 (MI355X): buffer repacking, the path-tracing kernel, accumulation.
+//
+// Numerics contract.  The reference's results are defined by how its GLSL is evaluated:
+// every + - * / separately rounded binary32, no contraction, except inside sin/cos/exp2/log2
+// where specific fused multiply-adds are part of the algorithm.  This file must therefore be
+// compiled with -ffp-contract=off and with correctly rounded fp32 divide/sqrt (hipcc's default);
+// fused operations are written explicitly as __builtin_fmaf.  Expression association below is
+// deliberate everywhere; do not "simplify" it.
+//
+// Reference: shaders/compute.glsl (main :451-688 and callees).
+
+#include "rt_internal.h"
+
+namespace rt {
+
+#define RT_BLOCK 256
+#define RT_STACK 48  // entries per lane; the reference's own array has 32 and no overflow guard
+
+// ------------------------------------------------------------------------------------------
+// scalar helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+
+struct v3 {
+    float x, y, z;
+};
+__device__ __forceinline__ v3 V(float x, float y, float z) { return v3{x, y, z}; }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ v3 operator/(v3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ v3 operator-(v3 a) { return V(-a.x, -a.y, -a.z); }
+// dot(vec3) association: x + (y + z)
+__device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+__device__ __forceinline__ v3 cross(v3 a, v3 b) {
+    return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ v3 normalize(v3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+__device__ __forceinline__ v3 reflect(v3 I, v3 N) { return I - N * (2.0f * dot(N, I)); }
+
+// ------------------------------------------------------------------------------------------
+// transcendental functions in the exact polynomial forms the reference's results come from
+// (they are not libm: see compute.glsl's use of pow/sin/cos at :358-361,:396-402,:553,:697,:705)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float d_exp2(float x) {
+    x = fminf(fmaxf(x, -127.0f), 128.0f);
+    float ip = floorf(x);
+    float fp = x - ip;
+    float x2 = fp * fp;
+    // even/odd split Horner, degree 5
+    float even = 0.00898934009049466391101f;
+    even = __builtin_fmaf(x2, even, 0.240153617044375388211f);
+    even = __builtin_fmaf(x2, even, 1.0f);
+    float odd = 0.00187757667519147912699f;
+    odd = __builtin_fmaf(x2, odd, 0.0558263180532956664775f);
+    odd = __builtin_fmaf(x2, odd, 0.693153073200168932794f);
+    float p = __builtin_fmaf(odd, fp, even);
+    uint32_t bits = (uint32_t)((int)ip + 127) << 23;
+    return u2f(bits) * p;
+}
+
+__device__ __forceinline__ float d_log2(float x) {
+    uint32_t i = f2u(x);
+    float e = (float)((int)((i >> 23) & 0xffu) - 127);
+    float m = u2f((i & 0x007fffffu) | 0x3f800000u);
+    float y = (m - 1.0f) / (m + 1.0f);
+    float z = y * y;
+    float z2 = z * z;
+    // even/odd split Horner, degree 4 in z
+    float even = 0.406718052498846252698f;
+    even = __builtin_fmaf(z2, even, 0.577440339438736392009f);
+    even = __builtin_fmaf(z2, even, 2.88539009343309178325f);
+    float odd = 0.403343858251329912514f;
+    odd = __builtin_fmaf(z2, odd, 0.961791550404184197881f);
+    float p = __builtin_fmaf(odd, z, even);
+    float r = __builtin_fmaf(y, p, e);
+    if (x >= __builtin_inff()) r = __builtin_inff();
+    if (x == 0.0f) r = -__builtin_inff();
+    if (x < 0.0f) r = __builtin_nanf("");
+    return r;
+}
+
+__device__ __forceinline__ float d_pow(float x, float y) { return d_exp2(d_log2(x) * y); }
+
+// sin and cos of the same angle (Cephes-style range reduction, both polynomials shared)
+__device__ __forceinline__ void d_sincos(float a, float &s_out, float &c_out) {
+    float x = fabsf(a);
+    int j = (int)(x * 1.27323954473516f);
+    j = (j + 1) & ~1;
+    float y = (float)j;
+    x = __builtin_fmaf(y, -0.78515625f, x);
+    x = __builtin_fmaf(y, -2.4187564849853515625e-4f, x);
+    x = __builtin_fmaf(y, -3.77489497744594108e-8f, x);
+    float z = x * x;
+    float yc = 2.443315711809948e-5f;
+    yc = __builtin_fmaf(yc, z, -1.388731625493765e-3f);
+    yc = __builtin_fmaf(yc, z, 4.166664568298827e-2f);
+    yc = yc * z;
+    yc = yc * z;
+    yc = __builtin_fmaf(z, -0.5f, yc);
+    yc = yc + 1.0f;
+    float ys = -1.9515295891e-4f;
+    ys = __builtin_fmaf(ys, z, 8.3321608736e-3f);
+    ys = __builtin_fmaf(ys, z, -1.6666654611e-1f);
+    ys = ys * z;
+    ys = __builtin_fmaf(ys, x, x);
+    uint32_t sign_s = (f2u(a) & 0x80000000u) ^ (((uint32_t)j & 4u) << 29);
+    bool sin_uses_sinpoly = ((j & 2) == 0);
+    int j2 = j - 2;
+    uint32_t sign_c = ((~(uint32_t)j2) & 4u) << 29;
+    bool cos_uses_sinpoly = ((j2 & 2) == 0);
+    s_out = u2f(f2u(sin_uses_sinpoly ? ys : yc) ^ sign_s);
+    c_out = u2f(f2u(cos_uses_sinpoly ? ys : yc) ^ sign_c);
+}
+
+// compute.glsl:701-706 and :693-698
+__device__ __forceinline__ float s2l(float c) {
+    if (c <= 0.04045f) return c / 12.92f;
+    return d_pow((c + 0.055f) / (1.0f + 0.055f), 2.4f);
+}
+__device__ __forceinline__ float l2s(float c) {
+    if (c <= 0.0031308f) return 12.92f * c;
+    return (1.0f + 0.055f) * d_pow(c, 1.0f / 2.4f) - 0.055f;
+}
+
+// compute.glsl:749-760
+__device__ __forceinline__ float draw(uint32_t &s) {
+    s = (s ^ 61u) ^ (s >> 16);
+    s *= 9u;
+    s = s ^ (s >> 4);
+    s *= 0x27d4eb2du;
+    s = s ^ (s >> 15);
+    return (float)s * (1.0f / 4294967296.0f);
+}
+
+// ------------------------------------------------------------------------------------------
+// repack kernels (run once per upload): reference layouts -> cache-line-aligned device records.
+// Every derived value is computed with exactly the operations the shader would apply per use,
+// so hoisting it here cannot change a result bit.
+// ------------------------------------------------------------------------------------------
+// BVH node, compute.glsl:244-261: f = float(q)/65535.0 ; coord = scene_min + f*scene_extent
+__global__ void repack_nodes_kernel(const uint32_t *__restrict__ src, uint32_t n, float3 smin, float3 sext,
+                                    float4 *__restrict__ dst) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    uint32_t w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = (i < n) ? src[(size_t)i * 16 + k] : 0u;
+    const float mn[3] = {smin.x, smin.y, smin.z}, ex[3] = {sext.x, sext.y, sext.z};
+    float lo[3][4], hi[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float l = (float)(w[4 * a + c] & 0xFFFFu) / 65535.0f;
+            float h = (float)(w[4 * a + c] >> 16) / 65535.0f;
+            lo[a][c] = mn[a] + l * ex[a];
+            hi[a][c] = mn[a] + h * ex[a];
+        }
+    float4 *o = dst + (size_t)i * kNodeVec;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        o[2 * a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+        o[2 * a + 1] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+    }
+    o[6] = make_float4(u2f(w[12]), u2f(w[13]), u2f(w[14]), u2f(w[15]));
+    o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Triangle, compute.glsl:880-881: edge1 = v1 - v0, edge2 = v2 - v0
+__global__ void repack_tris_kernel(const uint32_t *__restrict__ src, uint32_t n, float4 *__restrict__ dst) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    uint32_t w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = (i < n) ? src[(size_t)i * 16 + k] : 0u;
+    v3 v0 = V(u2f(w[0]), u2f(w[1]), u2f(w[2])), v1 = V(u2f(w[4]), u2f(w[5]), u2f(w[6])),
+       v2 = V(u2f(w[8]), u2f(w[9]), u2f(w[10]));
+    v3 e1 = v1 - v0, e2 = v2 - v0;
+    float4 *o = dst + (size_t)i * kTriVec;
+    o[0] = make_float4(v0.x, v0.y, v0.z, u2f(w[3]));
+    o[1] = make_float4(e1.x, e1.y, e1.z, u2f(w[12]));
+    o[2] = make_float4(e2.x, e2.y, e2.z, u2f(w[13]));
+    o[3] = make_float4(u2f(w[14]), 0.f, 0.f, 0.f);
+}
+
+__global__ void repack_spheres_kernel(const uint32_t *__restrict__ src, uint32_t n, float4 *__restrict__ dst) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = (i < n) ? src[(size_t)i * 8 + k] : 0u;
+    dst[(size_t)i * 2] = make_float4(u2f(w[0]), u2f(w[1]), u2f(w[2]), u2f(w[4]));
+    dst[(size_t)i * 2 + 1] = make_float4(u2f(w[5]), 0.f, 0.f, 0.f);
+}
+
+__global__ void copy_raw32_kernel(const uint32_t *__restrict__ src, uint32_t n, float4 *__restrict__ dst) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = (i < n) ? src[(size_t)i * 8 + k] : 0u;
+    dst[(size_t)i * 2] = make_float4(u2f(w[0]), u2f(w[1]), u2f(w[2]), u2f(w[3]));
+    dst[(size_t)i * 2 + 1] = make_float4(u2f(w[4]), u2f(w[5]), u2f(w[6]), u2f(w[7]));
+}
+
+// Material, compute.glsl:511-549.  The two mix(.., .., metallic) calls are evaluated in the
+// x*(1-t) + y*t form sharing (1 - metallic); pow(x, 2.0) is x*x.
+__global__ void repack_mats_kernel(const uint32_t *__restrict__ src, uint32_t n, float4 *__restrict__ dst) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    uint32_t c = (i < n) ? src[(size_t)i * 3] : 0u, e = (i < n) ? src[(size_t)i * 3 + 1] : 0u,
+             p = (i < n) ? src[(size_t)i * 3 + 2] : 0u;
+    v3 col = V(s2l((float)((c >> 21) & 0x7FFu) / 2047.0f), s2l((float)((c >> 10) & 0x7FFu) / 2047.0f),
+               s2l((float)(c & 0x3FFu) / 1023.0f));
+    float smooth = (float)(p & 0xFFu) / 255.0f;
+    float metal = (float)((p >> 8) & 0xFFu) / 255.0f;
+    float trans = (float)((p >> 16) & 0xFFu) / 255.0f;
+    float ior = ((float)((p >> 24) & 0xFFu) / 255.0f) * 3.0f;
+    v3 em = V(s2l((float)(e & 0xFFu) / 255.0f), s2l((float)((e >> 8) & 0xFFu) / 255.0f),
+              s2l((float)((e >> 16) & 0xFFu) / 255.0f));
+    float strength = (float)((e >> 24) & 0xFFu);
+    v3 emitted = em * strength;
+    float omm = 1.0f - metal;
+    v3 tint = V(omm + col.x * metal, omm + col.y * metal, omm + col.z * metal);
+    float q = (1.0f - ior) / (1.0f + ior);
+    float f0d = q * q;
+    float f0 = f0d * omm + metal;
+    v3 albedo = col * omm;
+    float rough = 1.0f - smooth;
+    float a = rough * rough;
+    float a2 = a * a;
+    float4 *o = dst + (size_t)i * kMatVec;
+    o[0] = make_float4(emitted.x, emitted.y, emitted.z, smooth);
+    o[1] = make_float4(tint.x, tint.y, tint.z, trans);
+    o[2] = make_float4(albedo.x, albedo.y, albedo.z, f0);
+    o[3] = make_float4(ior, a2, metal, 0.f);
+}
+
+static inline unsigned grid_for(uint32_t n_plus_sentinel) { return (n_plus_sentinel + 255u) / 256u; }
+
+void launch_repack_nodes(const uint32_t *src, uint32_t n, const float smin[3], const float sext[3], float4 *dst,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(repack_nodes_kernel, dim3(grid_for(n + 1)), dim3(256), 0, s, src, n,
+                       make_float3(smin[0], smin[1], smin[2]), make_float3(sext[0], sext[1], sext[2]), dst);
+}
+void launch_repack_tris(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s) {
+    hipLaunchKernelGGL(repack_tris_kernel, dim3(grid_for(n + 1)), dim3(256), 0, s, src, n, dst);
+}
+void launch_repack_spheres(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s) {
+    hipLaunchKernelGGL(repack_spheres_kernel, dim3(grid_for(n + 1)), dim3(256), 0, s, src, n, dst);
+}
+void launch_repack_mats(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s) {
+    hipLaunchKernelGGL(repack_mats_kernel, dim3(grid_for(n + 1)), dim3(256), 0, s, src, n, dst);
+}
+void launch_copy_raw32(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s) {
+    hipLaunchKernelGGL(copy_raw32_kernel, dim3(grid_for(n + 1)), dim3(256), 0, s, src, n, dst);
+}
+
+// ------------------------------------------------------------------------------------------
+// traversal (compute.glsl:225-330)
+// ------------------------------------------------------------------------------------------
+struct LaneStats {
+    uint32_t nodes, tri, sph, box, max_sp, overflow;
+};
+
+// compute.glsl:875-919 up to the distance; normal and position are derived after traversal
+__device__ __forceinline__ bool tri_distance(v3 O, v3 D, float4 r0, float4 r1, float4 r2, float &t_out) {
+    v3 v0 = V(r0.x, r0.y, r0.z), e1 = V(r1.x, r1.y, r1.z), e2 = V(r2.x, r2.y, r2.z);
+    v3 p = cross(D, e2);
+    float det = dot(e1, p);
+    if (fabsf(det) < 1e-6f) return false;
+    float inv = 1.0f / det;
+    v3 tv = O - v0;
+    float u = dot(tv, p) * inv;
+    if (u < 0.0f || u > 1.0f) return false;
+    v3 q = cross(tv, e1);
+    float v = dot(D, q) * inv;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = dot(e2, q) * inv;
+    if (t <= 0.0f) return false;
+    t_out = t;
+    return true;
+}
+
+// compute.glsl:808-836
+__device__ __forceinline__ bool sphere_distance(v3 O, v3 D, float4 s0, float &t_out) {
+    v3 L = V(s0.x, s0.y, s0.z) - O;
+    float tca = dot(L, D);
+    float d2 = dot(L, L) - tca * tca;
+    if (d2 > s0.w) return false;
+    float thc = sqrtf(s0.w - d2);
+    float t0 = tca - thc, t1 = tca + thc;
+    if (t0 > t1) {
+        float tmp = t0;
+        t0 = t1;
+        t1 = tmp;
+    }
+    if (t0 < 0.0f) {
+        t0 = t1;
+        if (t0 < 0.0f) return false;
+    }
+    t_out = t0;
+    return true;
+}
+
+// compute.glsl:921-942
+__device__ __forceinline__ bool box_distance(v3 O, v3 D, v3 b0, v3 b1, float &t_out) {
+    v3 inv = V(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+    v3 tbot = inv * (b0 - O), ttop = inv * (b1 - O);
+    v3 tmin = V(fminf(ttop.x, tbot.x), fminf(ttop.y, tbot.y), fminf(ttop.z, tbot.z));
+    v3 tmax = V(fmaxf(ttop.x, tbot.x), fmaxf(ttop.y, tbot.y), fmaxf(ttop.z, tbot.z));
+    float t0 = fmaxf(fmaxf(tmin.x, tmin.y), fmaxf(tmin.x, tmin.z));
+    float t1 = fminf(fminf(tmax.x, tmax.y), fminf(tmax.x, tmax.z));
+    if (t1 <= fmaxf(t0, 0.0f)) return false;
+    t_out = t0;
+    return true;
+}
+
+#define CSWAP(ka, kb, ma, mb, va, vb)  \
+    {                                  \
+        bool sw_ = (kb < ka);          \
+        float tk_ = sw_ ? kb : ka;     \
+        kb = sw_ ? ka : kb;            \
+        ka = tk_;                      \
+        uint32_t tm_ = sw_ ? mb : ma;  \
+        mb = sw_ ? ma : mb;            \
+        ma = tm_;                      \
+        bool tv_ = sw_ ? vb : va;      \
+        vb = sw_ ? va : vb;            \
+        va = tv_;                      \
+    }
+
+// Returns the distance of the best hit (1e38 if none) and the metadata word of the primitive
+// that produced it.  `stack` points at this lane's column of the LDS stack (stride RT_BLOCK).
+template <bool STATS>
+__device__ __forceinline__ float traverse(const DevScene &sc, v3 O, v3 D, v3 ID, uint32_t &best_code,
+                                          uint32_t *stack, LaneStats &st) {
+    float best = 1e38f;
+    best_code = 0xFFFFFFFFu;
+    int sp = 0;
+    stack[0] = 0u;
+    sp = 1;
+    while (sp > 0) {
+        if (STATS) {
+            st.max_sp = max(st.max_sp, (uint32_t)sp);
+            st.nodes++;
+        }
+        uint32_t ni = stack[(--sp) * RT_BLOCK];
+        ni = min(ni, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
+        const float4 *np = sc.nodes + (size_t)ni * kNodeVec;
+        float4 lox = np[0], hix = np[1], loy = np[2], hiy = np[3], loz = np[4], hiz = np[5], mt = np[6];
+        float k0, k1, k2, k3;
+        bool v0, v1, v2, v3_;
+        // compute.glsl:186-208, one child per macro expansion
+#define SLAB(c, KEY, VAL)                                                           \
+    {                                                                               \
+        float t1x = (lox.c - O.x) * ID.x, t2x = (hix.c - O.x) * ID.x;               \
+        float t1y = (loy.c - O.y) * ID.y, t2y = (hiy.c - O.y) * ID.y;               \
+        float t1z = (loz.c - O.z) * ID.z, t2z = (hiz.c - O.z) * ID.z;               \
+        float tN = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f)); \
+        float tF = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z)); \
+        KEY = tN;                                                                   \
+        VAL = (tN <= tF) && (tN < best);                                            \
+    }
+        SLAB(x, k0, v0) SLAB(y, k1, v1) SLAB(z, k2, v2) SLAB(w, k3, v3_)
+#undef SLAB
+        uint32_t m0 = f2u(mt.x), m1 = f2u(mt.y), m2 = f2u(mt.z), m3 = f2u(mt.w);
+        // compute.glsl:210-223
+        CSWAP(k0, k1, m0, m1, v0, v1)
+        CSWAP(k2, k3, m2, m3, v2, v3_)
+        CSWAP(k0, k2, m0, m2, v0, v2)
+        CSWAP(k1, k3, m1, m3, v1, v3_)
+        CSWAP(k1, k2, m1, m2, v1, v2)
+        // compute.glsl:290-326: far to near
+#define VISIT(VAL, META)                                                                          \
+    if (VAL) {                                                                                    \
+        uint32_t type = META >> 30, idx = META & 0x3FFFFFFFu;                                     \
+        if (type == 3u) {                                                                         \
+            if (sp < RT_STACK) {                                                                  \
+                stack[sp * RT_BLOCK] = idx;                                                       \
+                sp++;                                                                             \
+            } else {                                                                              \
+                st.overflow++;                                                                    \
+            }                                                                                     \
+        } else {                                                                                  \
+            float t;                                                                              \
+            bool hit;                                                                             \
+            if (type == 0u) {                                                                     \
+                const float4 *tp = sc.tris + (size_t)min(idx, sc.n_tris) * kTriVec;               \
+                if (STATS) st.tri++;                                                              \
+                hit = tri_distance(O, D, tp[0], tp[1], tp[2], t);                                 \
+            } else if (type == 1u) {                                                              \
+                const float4 *spn = sc.spheres + (size_t)min(idx, sc.n_spheres) * kSphereVec;     \
+                if (STATS) st.sph++;                                                              \
+                hit = sphere_distance(O, D, spn[0], t);                                           \
+            } else {                                                                              \
+                const float4 *bp = sc.boxes + (size_t)min(idx, sc.n_boxes) * 2;                   \
+                float4 b0 = bp[0], b1 = bp[1];                                                    \
+                if (STATS) st.box++;                                                              \
+                hit = box_distance(O, D, V(b0.x, b0.y, b0.z), V(b1.x, b1.y, b1.z), t);            \
+            }                                                                                     \
+            if (hit && t > 0.0f && t < best - 1e-6f) {                                            \
+                best = t;                                                                         \
+                best_code = META;                                                                 \
+            }                                                                                     \
+        }                                                                                         \
+    }
+        VISIT(v3_, m3) VISIT(v2, m2) VISIT(v1, m1) VISIT(v0, m0)
+#undef VISIT
+    }
+    return best;
+}
+
+// Surface attributes of the accepted primitive, derived from (O, D, t, code) exactly as the
+// intersection routines derive them (compute.glsl:838-843, :909-916, :944-961).
+__device__ __forceinline__ void hit_attributes(const DevScene &sc, v3 O, v3 D, float t, uint32_t code, v3 &pos,
+                                               v3 &n, uint32_t &mat) {
+    uint32_t type = code >> 30, idx = code & 0x3FFFFFFFu;
+    pos = O + D * t;
+    if (type == 0u) {
+        const float4 *tp = sc.tris + (size_t)min(idx, sc.n_tris) * kTriVec;
+        float4 r0 = tp[0], r1 = tp[1], r2 = tp[2], r3 = tp[3];
+        n = V(r1.w, r2.w, r3.x);
+        mat = f2u(r0.w);
+        if (dot(D, n) > 0.0f) n = -n;
+    } else if (type == 1u) {
+        const float4 *spn = sc.spheres + (size_t)min(idx, sc.n_spheres) * kSphereVec;
+        float4 s0 = spn[0], s1 = spn[1];
+        n = normalize(pos - V(s0.x, s0.y, s0.z));
+        mat = f2u(s1.x);
+        if (dot(D, n) > 0.0f) n = -n;
+    } else {
+        const float4 *bp = sc.boxes + (size_t)min(idx, sc.n_boxes) * 2;
+        float4 b0 = bp[0], b1 = bp[1];
+        mat = f2u(b0.w);
+        const float e = 0.00001f;
+        n = V(0.f, 0.f, 0.f);  // the reference leaves it undefined when no face is within epsilon
+        if (fabsf(pos.x - b0.x) < e) n = V(-1.f, 0.f, 0.f);
+        else if (fabsf(pos.x - b1.x) < e) n = V(1.f, 0.f, 0.f);
+        else if (fabsf(pos.y - b0.y) < e) n = V(0.f, -1.f, 0.f);
+        else if (fabsf(pos.y - b1.y) < e) n = V(0.f, 1.f, 0.f);
+        else if (fabsf(pos.z - b0.z) < e) n = V(0.f, 0.f, -1.f);
+        else if (fabsf(pos.z - b1.z) < e) n = V(0.f, 0.f, 1.f);
+    }
+}
+
+// compute.glsl:767-805; the loop bound is inclusive, the extra record reads as zeros
+__device__ __forceinline__ void planes_nearest(const DevScene &sc, v3 O, v3 D, bool &exists, float &t_best, v3 &pos,
+                                               v3 &n, uint32_t &mat) {
+    exists = false;
+    t_best = 9999999.0f;
+    for (uint32_t i = 0; i <= sc.n_planes; i++) {
+        float4 p0 = sc.planes[(size_t)i * 2], p1 = sc.planes[(size_t)i * 2 + 1];
+        v3 pp = V(p0.x, p0.y, p0.z), pn = V(p1.x, p1.y, p1.z);
+        float denom = dot(pn, D);
+        if (-denom > 0.0000001f) {
+            float t = dot(pp - O, pn) / denom;
+            if (t > 0.0f && t < t_best) {
+                exists = true;
+                t_best = t;
+                n = pn;
+                pos = O + D * t;
+                mat = f2u(p0.w);
+            }
+        }
+    }
+}
+
+// compute.glsl:392-406, :381-388, :577.  sin_theta is sqrt(1 - x) with x the argument of
+// cos_theta's square root (sqrt(x)*sqrt(x) folds to x), and 1 + (a2-1)*g2 is (1-g2) + a2*g2.
+__device__ __forceinline__ v3 ggx_half_vector(v3 n, float a2, float g1, float g2) {
+    float phi = (2.0f * 3.14159265f) * g1;
+    float omg = 1.0f - g2;
+    float ct2 = omg / (omg + a2 * g2);
+    float ct = sqrtf(ct2);
+    float st = sqrtf(1.0f - fabsf(ct2));
+    float sn, cs;
+    d_sincos(phi, sn, cs);
+    float hx = cs * st, hy = sn * st, hz = ct;
+    v3 T;
+    if (fabsf(n.x) > fabsf(n.y)) T = V(-n.z, 0.0f, n.x) / sqrtf(n.x * n.x + n.z * n.z);
+    else T = V(0.0f, n.z, -n.y) / sqrtf(n.y * n.y + n.z * n.z);
+    v3 B = cross(n, T);
+    return normalize((T * hx + B * hy) + n * hz);
+}
+
+// ------------------------------------------------------------------------------------------
+// the path-tracing kernel: one lane = one pixel-sample (compute.glsl:451-688)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t morton2(uint32_t x, uint32_t y) {
+    auto part = [](uint32_t v) {
+        v &= 0xFFFFu;
+        v = (v | (v << 8)) & 0x00FF00FFu;
+        v = (v | (v << 4)) & 0x0F0F0F0Fu;
+        v = (v | (v << 2)) & 0x33333333u;
+        v = (v | (v << 1)) & 0x55555555u;
+        return v;
+    };
+    return part(x) | (part(y) << 1);
+}
+
+template <int MODE, bool AUX, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void trace_kernel(TraceParams p) {
+    __shared__ uint32_t lds_stack[RT_STACK * RT_BLOCK];
+    const DevScene &sc = p.scene;
+    // 16x16 pixel tile per workgroup, 8x8 per wavefront.  Workgroups that share an XCD (equal
+    // blockIdx % 8 under round-robin placement) get a contiguous run of tiles so that their
+    // node working sets overlap in that XCD's L2.
+    uint32_t b = blockIdx.x;
+    uint32_t per = (p.ntiles + 7u) / 8u;
+    uint32_t tile = (b & 7u) * per + (b >> 3);
+    if (tile >= p.ntiles) return;
+    uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    int x = (int)(tx * 16u + (wave & 1u) * 8u + (lane & 7u));
+    int y = (int)(ty * 16u + (wave >> 1) * 8u + (lane >> 3));
+    bool live = (x < p.WW) && (y < p.HH);
+    if (MODE == 1 && p.nshards > 1u) {
+        // 64x64 pixel macro tiles dealt round-robin in Morton order
+        uint32_t owner = morton2((uint32_t)x >> 6, (uint32_t)y >> 6) % p.nshards;
+        live = live && (owner == p.shard);
+    }
+    uint32_t *stack = lds_stack + threadIdx.x;
+    LaneStats st = {0, 0, 0, 0, 0, 0};
+    uint32_t nrays = 0;
+    if (live) {
+        const int W = p.W, H = p.H;
+        float px = (float)(2 * x - W) / (float)W;
+        float py = (float)(2 * y - H) / (float)H;
+        uint32_t state = ((uint32_t)x * 1973u + (uint32_t)y * 9277u + (uint32_t)(p.time * 1000.0f) * 26699u) | 1u;
+        float jx = draw(state) - 0.5f;
+        float jy = draw(state) - 0.5f;
+        float qx = px + jx / (float)W;
+        float qy = py + jy / (float)H;
+        const float *M = sc.inv_vp;
+        float far4[4], near4[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            far4[r] = ((M[r] * qx + M[4 + r] * qy) + M[8 + r] * 1.0f) + M[12 + r] * 1.0f;
+            near4[r] = ((M[r] * qx + M[4 + r] * qy) + M[8 + r] * 0.0f) + M[12 + r] * 1.0f;
+        }
+        v3 farp = V(far4[0] / far4[3], far4[1] / far4[3], far4[2] / far4[3]);
+        v3 nearp = V(near4[0] / near4[3], near4[1] / near4[3], near4[2] / near4[3]);
+        v3 D = normalize(farp - nearp);
+        v3 O = V(sc.eye[0], sc.eye[1], sc.eye[2]);
+        v3 ID = V(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+        float ray_ior = 1.0f;
+        v3 thr = V(1.f, 1.f, 1.f), light = V(0.f, 0.f, 0.f);
+        const uint32_t nb = (uint32_t)p.bounces;
+        uint32_t aux0 = 0xFFFFFFFFu, aux1 = 0u, aux2 = 0u;
+        for (uint32_t i = 0; i < nb; i++) {
+            uint32_t code;
+            float tb = traverse<STATS>(sc, O, D, ID, code, stack, st);
+            nrays++;
+            // compute.glsl:332-351: the BVH hit wins only if nearer than the nearest plane hit
+            bool p_exists;
+            float tp;
+            v3 ppos, pn;
+            uint32_t pmat;
+            planes_nearest(sc, O, D, p_exists, tp, ppos, pn, pmat);
+            bool exists;
+            v3 pos, n;
+            uint32_t mat;
+            float thit;
+            if (tb < tp) {
+                exists = true;  // best < 9999999 implies a primitive was accepted
+                thit = tb;
+                hit_attributes(sc, O, D, tb, code, pos, n, mat);
+            } else {
+                exists = p_exists;
+                thit = tp;
+                pos = ppos;
+                n = pn;
+                mat = pmat;
+            }
+            if (AUX && i == 0) {
+                aux0 = code;
+                aux1 = f2u(thit);
+                aux2 = exists ? 1u : 0u;
+            }
+            if (!exists) break;
+            const float4 *mp = sc.mats + (size_t)min(mat, sc.n_mats) * kMatVec;
+            float4 q0 = mp[0], q1 = mp[1], q2 = mp[2], q3 = mp[3];
+            float smooth = q0.w, trans = q1.w, f0 = q2.w, ior = q3.x, a2 = q3.y;
+            light = light + V(q0.x, q0.y, q0.z) * thr;
+            float cosT = fminf(dot(-D, n), 1.0f);
+            float R = f0 + (1.0f - f0) * d_pow(1.0f - cosT, 5.0f);
+            v3 Dn;
+            if (draw(state) < R) {
+                if (smooth == 1.0f) {
+                    Dn = reflect(D, n);
+                } else {
+                    float g1 = draw(state), g2 = draw(state);
+                    v3 Hh = ggx_half_vector(n, a2, g1, g2);
+                    Dn = reflect(D, Hh);
+                }
+                O = pos + Dn * 0.0001f;
+                thr = thr * V(q1.x, q1.y, q1.z);
+            } else if (draw(state) < trans) {
+                bool entering = dot(D, n) < 0.0f;
+                v3 nn = entering ? n : -n;
+                float n1 = ray_ior, n2 = entering ? ior : 1.0f;
+                float g1 = draw(state), g2 = draw(state);
+                v3 Hh = ggx_half_vector(n, a2, g1, g2);
+                float eta = n1 / n2;
+                float dn = dot(Hh, D);
+                float k = 1.0f - eta * (eta * (1.0f - dn * dn));
+                v3 r = V(0.f, 0.f, 0.f);
+                if (!(k < 0.0f)) r = D * eta - Hh * (eta * dn + sqrtf(k));
+                if (dot(r, r) == 0.0f) {
+                    Dn = reflect(D, nn);
+                } else {
+                    Dn = r;
+                    ray_ior = n2;
+                }
+                O = pos + Dn * 0.0001f;
+            } else {
+                float u1 = draw(state), u2 = draw(state);
+                float rr = sqrtf(u2);
+                float th = (2.0f * 3.14159265f) * u1;
+                float sn, cs;
+                d_sincos(th, sn, cs);
+                float sx = rr * cs, sy = rr * sn, sz = sqrtf(fmaxf(0.0f, 1.0f - u2));
+                v3 tg;
+                if (fabsf(n.x) > fabsf(n.y)) {
+                    v3 t0 = V(n.z, 0.0f, -n.x);
+                    tg = t0 / sqrtf(dot(t0, t0));
+                } else {
+                    v3 t0 = V(0.0f, -n.z, n.y);
+                    tg = t0 / sqrtf(dot(t0, t0));
+                }
+                v3 bt = cross(n, tg);
+                v3 dif = (tg * sx + bt * sy) + n * sz;
+                float dDn = dot(D, n);
+                v3 spec = normalize(D - (n * 2.0f) * dDn);
+                O = pos + n * 0.0001f;
+                Dn = V(dif.x + smooth * (spec.x - dif.x), dif.y + smooth * (spec.y - dif.y),
+                       dif.z + smooth * (spec.z - dif.z));
+                if (dot(Dn, n) < 0.0f) Dn = -Dn;
+                thr = thr * V(q2.x, q2.y, q2.z);
+            }
+            D = Dn;
+            ID = V(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+            // compute.glsl:428-445
+            if (i >= 3u) {
+                if (i >= 64u) break;
+                float lum = dot(thr, V(0.2126f, 0.7152f, 0.0722f));
+                float pr = fminf(fmaxf(lum, 0.05f), 0.95f);
+                if (draw(state) > pr) break;
+                thr = thr / pr;
+            }
+        }
+        size_t pix = (size_t)y * W + x;
+        if (MODE == 0) {
+            if (p.sample) p.sample[pix] = make_float4(l2s(light.x), l2s(light.y), l2s(light.z), 1.0f);
+        } else {
+            float4 s = p.sum[pix];
+            p.sum[pix] = make_float4(s.x + light.x, s.y + light.y, s.z + light.z, s.w + 1.0f);
+        }
+        if (AUX) {
+            uint4 *a = reinterpret_cast<uint4 *>(p.aux + pix * 16);
+            a[0] = make_uint4(aux0, aux1, aux2, st.nodes);
+            a[1] = make_uint4(f2u(D.x), f2u(D.y), f2u(D.z), f2u(O.x));
+            a[2] = make_uint4(f2u(O.y), f2u(O.z), f2u(thr.x), f2u(thr.y));
+            a[3] = make_uint4(f2u(thr.z), state, nrays, f2u(ray_ior));
+        }
+    }
+    // counters: one atomic per wavefront per counter
+    auto wave_sum = [](uint32_t v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    auto wave_max = [](uint32_t v) {
+        for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o));
+        return v;
+    };
+    uint32_t r = wave_sum(nrays), ps = wave_sum(live ? 1u : 0u), ov = wave_sum(st.overflow);
+    if (lane == 0) {
+        if (r) atomicAdd(&p.counters->rays, (unsigned long long)r);
+        if (ps) atomicAdd(&p.counters->pixel_samples, (unsigned long long)ps);
+        if (ov) atomicAdd(&p.counters->stack_overflows, (unsigned long long)ov);
+    }
+    if (STATS) {
+        uint32_t a = wave_sum(st.nodes), t3 = wave_sum(st.tri), s3 = wave_sum(st.sph), b3 = wave_sum(st.box),
+                 m = wave_max(st.max_sp);
+        if (lane == 0) {
+            atomicAdd(&p.counters->nodes, (unsigned long long)a);
+            atomicAdd(&p.counters->tri_tests, (unsigned long long)t3);
+            atomicAdd(&p.counters->sphere_tests, (unsigned long long)s3);
+            atomicAdd(&p.counters->box_tests, (unsigned long long)b3);
+            atomicMax(&p.counters->max_stack, (unsigned long long)m);
+        }
+    }
+}
+
+void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s) {
+    // grid: tiles rounded up to a multiple of 8 so the XCD-contiguous remap is a bijection onto
+    // [0, 8*ceil(ntiles/8)) with the surplus workgroups exiting at once
+    uint32_t per = (p.ntiles + 7u) / 8u;
+    if (per == 0) return;  // image smaller than one dispatch group: the reference dispatches nothing
+    dim3 grid(per * 8u), block(RT_BLOCK);
+#define L(M, A, S) hipLaunchKernelGGL((trace_kernel<M, A, S>), grid, block, 0, s, p)
+    if (mode == 0) {
+        if (aux && stats) L(0, true, true);
+        else if (aux) L(0, true, false);
+        else if (stats) L(0, false, true);
+        else L(0, false, false);
+    } else {
+        if (stats) L(1, false, true);
+        else L(1, false, false);
+    }
+#undef L
+}
+
+// ------------------------------------------------------------------------------------------
+// accumulate pass (shaders/screen_fragment.glsl:94-108) and sum finalisation
+// ------------------------------------------------------------------------------------------
+__global__ void accumulate_kernel(const float4 *__restrict__ sample, float4 *__restrict__ acc, size_t n,
+                                  float frames) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float w = 1.0f / (frames + 1.0f);
+    float4 s = sample[i], a = acc[i];
+    float ar = s2l(a.x), ag = s2l(a.y), ab = s2l(a.z);
+    float sr = s2l(s.x), sg = s2l(s.y), sb = s2l(s.z);
+    acc[i] = make_float4(l2s(ar + w * (sr - ar)), l2s(ag + w * (sg - ag)), l2s(ab + w * (sb - ab)), 1.0f);
+}
+
+__global__ void finalize_sum_kernel(const float4 *__restrict__ sum, float4 *__restrict__ acc, size_t n, float spp) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 s = sum[i];
+    acc[i] = make_float4(l2s(s.x / spp), l2s(s.y / spp), l2s(s.z / spp), 1.0f);
+}
+
+void launch_accumulate(const float4 *sample, float4 *acc, size_t npixels, float frames, hipStream_t s) {
+    hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((npixels + 255) / 256)), dim3(256), 0, s, sample, acc,
+                       npixels, frames);
+}
+void launch_finalize_sum(const float4 *sum, float4 *acc, size_t npixels, uint32_t spp, hipStream_t s) {
+    hipLaunchKernelGGL(finalize_sum_kernel, dim3((unsigned)((npixels + 255) / 256)), dim3(256), 0, s, sum, acc,
+                       npixels, (float)spp);
+}
+
+}  // namespace rt

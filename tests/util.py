@@ -1,0 +1,37 @@
+"""Shared helpers for the tests: loading a golden scene into the HIP renderer."""
+
+import hashlib
+from pathlib import Path
+
+import numpy as np
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def sha(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def load_golden_scene(renderer, scene: str):
+    """Uploads the byte buffers of tests/golden/<scene> in the reference loader's order
+    (materials 9, spheres 5, triangles 12, BVH 11; reference scene.py:97,122,193,62)."""
+    d = GOLDEN / scene
+    for name, binding in (("mats.bin", 9), ("spheres.bin", 5), ("tris.bin", 12), ("bvh.bin", 11)):
+        data = np.fromfile(d / name, dtype=np.uint8) if (d / name).exists() else np.zeros(0, np.uint8)
+        renderer.update_ssbo(0, data, binding)
+    u = np.fromfile(d / "uniforms.bin", dtype=np.float32)
+    renderer.set_uniforms(u[0:16], u[16:19])
+    renderer.scene_min_coords = u[19:22]
+    renderer.scene_extent = u[22:25]
+    return u
+
+
+def render_frame(renderer, w, h, frame, bounces, aux=False, stats=False):
+    if (renderer.width, renderer.height) != (w, h):
+        renderer.update_size(w, h)
+    renderer.bounces = bounces
+    renderer.set_frame_index(frame)
+    renderer.set_flags(aux=aux, stats=stats)
+    renderer.camera.changed = False
+    renderer.render()
+    return renderer.read_sample()
