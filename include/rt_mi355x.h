@@ -40,8 +40,7 @@ enum {
 /* rt_render flags */
 enum {
     RT_FLAG_AUX = 1u,        /* also record the 16-word per-pixel parity record (rt_read_aux)   */
-    RT_FLAG_STATS = 2u,      /* also count node visits and primitive tests (slower)              */
-    RT_FLAG_NO_SAMPLE = 4u   /* do not store the per-frame sample image, only the accumulation   */
+    RT_FLAG_STATS = 2u       /* also count node visits and primitive tests (slower)              */
 };
 
 typedef struct {
@@ -53,6 +52,7 @@ typedef struct {
     uint64_t box_tests;     /* box tests             (RT_FLAG_STATS only)                        */
     uint64_t max_stack;     /* deepest traversal stack seen (RT_FLAG_STATS only)                 */
     uint64_t stack_overflows; /* pushes dropped because the stack was full (always counted)      */
+    uint64_t hits;          /* rays that hit a surface (RT_FLAG_STATS only)                      */
     double last_render_ms;  /* device time of the last rt_render / rt_render_sum call            */
     double last_trace_ms;   /* device time spent in the trace kernel(s) of that call             */
 } rt_stats;

@@ -76,6 +76,11 @@ def write_scene(name: str, toml_text: str, meshes, camera: Camera | None = None,
     sdir.mkdir(parents=True, exist_ok=True)
     scene = tomli.loads(toml_text)
     mesh_tris = [(refscene.read_obj_triangles(REF / "models" / m), mat) for m, mat in meshes]
+    # inputs as data, so that the scene pipeline can be tested where the reference is absent
+    (sdir / "scene.json").write_text(json.dumps(scene, indent=1))
+    (GOLD / "meshes").mkdir(exist_ok=True)
+    for (m, _), (arr, _) in zip(meshes, mesh_tris):
+        np.savez_compressed(GOLD / "meshes" / (Path(m).stem + ".npz"), triangles=arr)
     b = refscene.build_reference_scene(scene, mesh_tris)
     cam = camera or Camera()
     inv_vp, eye = cam.uniforms_f32()
@@ -234,10 +239,28 @@ def main():
     if want("matlab"):
         toml = matlab_toml()
         s = write_scene("matlab", toml, [("gally.obj", 9 + 29), ("box.obj", 9 + 14)])
-        (s / "scene.toml").write_text(toml)
         golden_frames(s, "small_160x88_b6", 160, 88, 6, 0, 2, T, store_full=True, kinds=("color", "primary"))
         golden_frames(s, "mid_640x360_b5", 640, 360, 5, 0, 3, T, store_full=False, kinds=("color", "primary", "counters"))
         golden_state(s, "state_160x88_b4_f1", 160, 88, 4, 1, T)
+    if want("big"):
+        # byte-level pins for the native scene pipeline on large inputs: only hashes are kept
+        from raytracer_amd import synth
+        big = {}
+        scene, meshes = synth.sponza_synth(1.0)
+        b = refscene.build_reference_scene(scene, meshes)
+        big["sponza_synth"] = {"detail": 1.0, "triangles": len(b["tris"]) // 64, "nodes": len(b["bvh"]) // 64,
+                               "sha256": {k: sha(b[k]) for k in ("mats", "spheres", "tris", "bvh")},
+                               "scene_min": [float(x) for x in b["scene_min"]],
+                               "scene_extent": [float(x) for x in b["scene_extent"]]}
+        scene = tomli.loads(test_toml_with_mesh())
+        sph_tris = refscene.read_obj_triangles(REF / "models" / "sphere.obj")
+        np.savez_compressed(GOLD / "meshes" / "sphere.npz", triangles=sph_tris)
+        b = refscene.build_reference_scene(scene, [(sph_tris, 26)])
+        big["test_sphere_obj"] = {"triangles": len(b["tris"]) // 64, "nodes": len(b["bvh"]) // 64,
+                                  "sha256": {k: sha(b[k]) for k in ("mats", "spheres", "tris", "bvh")},
+                                  "scene_min": [float(x) for x in b["scene_min"]],
+                                  "scene_extent": [float(x) for x in b["scene_extent"]]}
+        (GOLD / "big_scene_hashes.json").write_text(json.dumps(big, indent=1))
     print("done")
 
 

@@ -21,12 +21,11 @@ SYMBOLS = (
 
 RT_FLAG_AUX = 1
 RT_FLAG_STATS = 2
-RT_FLAG_NO_SAMPLE = 4
 
 
 class RtStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "pixel_samples", "nodes", "tri_tests", "sphere_tests", "box_tests",
-                                           "max_stack", "stack_overflows")] + [("last_render_ms", C.c_double),
+                                           "max_stack", "stack_overflows", "hits")] + [("last_render_ms", C.c_double),
                                                                                ("last_trace_ms", C.c_double)]
 
 

@@ -362,6 +362,7 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
     out->box_tests = h.box_tests;
     out->max_stack = h.max_stack;
     out->stack_overflows = h.stack_overflows;
+    out->hits = h.hits;
     out->last_render_ms = 0.0;
     out->last_trace_ms = 0.0;
     if (c->timed) {

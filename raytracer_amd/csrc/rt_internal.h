@@ -38,7 +38,8 @@ struct DevScene {
 
 struct Counters {  // lives in device memory, 16 x u64
     unsigned long long rays, pixel_samples, nodes, tri_tests, sphere_tests, box_tests, max_stack, stack_overflows;
-    unsigned long long pad[8];
+    unsigned long long hits;
+    unsigned long long pad[7];
 };
 
 struct TraceParams {

@@ -263,7 +263,7 @@ void launch_copy_raw32(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t
 // traversal (compute.glsl:225-330)
 // ------------------------------------------------------------------------------------------
 struct LaneStats {
-    uint32_t nodes, tri, sph, box, max_sp, overflow;
+    uint32_t nodes, tri, sph, box, max_sp, overflow, hits;
 };
 
 // compute.glsl:875-919 up to the distance; normal and position are derived after traversal
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_kernel(TraceParams p) {
         live = live && (owner == p.shard);
     }
     uint32_t *stack = lds_stack + threadIdx.x;
-    LaneStats st = {0, 0, 0, 0, 0, 0};
+    LaneStats st = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0;
     if (live) {
         const int W = p.W, H = p.H;
@@ -582,6 +582,7 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_kernel(TraceParams p) {
                 aux2 = exists ? 1u : 0u;
             }
             if (!exists) break;
+            if (STATS) st.hits++;
             const float4 *mp = sc.mats + (size_t)min(mat, sc.n_mats) * kMatVec;
             float4 q0 = mp[0], q1 = mp[1], q2 = mp[2], q3 = mp[3];
             float smooth = q0.w, trans = q1.w, f0 = q2.w, ior = q3.x, a2 = q3.y;
@@ -685,13 +686,14 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_kernel(TraceParams p) {
     }
     if (STATS) {
         uint32_t a = wave_sum(st.nodes), t3 = wave_sum(st.tri), s3 = wave_sum(st.sph), b3 = wave_sum(st.box),
-                 m = wave_max(st.max_sp);
+                 m = wave_max(st.max_sp), h3 = wave_sum(st.hits);
         if (lane == 0) {
             atomicAdd(&p.counters->nodes, (unsigned long long)a);
             atomicAdd(&p.counters->tri_tests, (unsigned long long)t3);
             atomicAdd(&p.counters->sphere_tests, (unsigned long long)s3);
             atomicAdd(&p.counters->box_tests, (unsigned long long)b3);
             atomicMax(&p.counters->max_stack, (unsigned long long)m);
+            atomicAdd(&p.counters->hits, (unsigned long long)h3);
         }
     }
 }

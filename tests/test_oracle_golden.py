@@ -21,7 +21,7 @@ def _cases(golden):
     out = []
     for sdir in sorted(p for p in golden.iterdir() if p.is_dir()):
         for j in sorted(sdir.glob("*.json")):
-            if j.name == "meta.json" or j.name.endswith(".state.json"):
+            if j.name in ("meta.json", "scene.json") or j.name.endswith(".state.json"):
                 continue
             out.append((sdir.name, j.stem))
     return out
