@@ -8,8 +8,11 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+import os
+
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "librt_mi355x.so"
+# RT_MI355X_LIB selects another build of the same library (kernel A/B experiments)
+LIB_PATH = Path(os.environ.get("RT_MI355X_LIB", HERE / "librt_mi355x.so"))
 
 # every symbol include/rt_mi355x.h declares
 SYMBOLS = (

@@ -6,6 +6,7 @@
 #include "rt_internal.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -53,6 +54,11 @@ struct rt_ctx {
     std::vector<hipEvent_t> ev_trace;  // pairs around trace kernels of the last call
     size_t ev_trace_used = 0;
     bool timed = false;
+    // scheduling of the frame: 0 = megakernel, 1 = wavefront (ray queues, persistent traversal)
+    int pipeline = 1;
+    rt::WaveQueues q = {{nullptr, nullptr}, nullptr, nullptr, nullptr};
+    uint32_t extend_waves = 8192;
+    uint32_t refill_threshold = 16;
 };
 
 namespace {
@@ -102,8 +108,25 @@ int alloc_images(rt_ctx *c) {
         HIP_TRY(hipFree(c->aux));
         c->aux = nullptr;
     }
+    // ray queues of the wavefront pipeline: at most one ray per pixel per bounce
+    for (void **p : {(void **)&c->q.rays[0], (void **)&c->q.rays[1], (void **)&c->q.hits, (void **)&c->q.paths}) {
+        if (*p) HIP_TRY(hipFree(*p));
+        *p = nullptr;
+    }
+    HIP_TRY(hipMalloc((void **)&c->q.rays[0], n * 2 * sizeof(float4)));
+    HIP_TRY(hipMalloc((void **)&c->q.rays[1], n * 2 * sizeof(float4)));
+    HIP_TRY(hipMalloc((void **)&c->q.hits, n * sizeof(float2)));
+    HIP_TRY(hipMalloc((void **)&c->q.paths, n * 2 * sizeof(float4)));
     c->rendered_frames = 0;
     return 0;
+}
+
+// one frame on the context's stream with the selected pipeline
+void trace_frame(rt_ctx *c, const rt::TraceParams &p, int mode, bool aux, bool stats) {
+    if (c->pipeline == 0)
+        rt::launch_trace(p, mode, aux, stats, c->stream);
+    else
+        rt::launch_wavefront_frame(p, c->q, mode, aux, stats, c->extend_waves, c->refill_threshold, c->stream);
 }
 
 // brings the device records of one binding up to date
@@ -208,6 +231,18 @@ int rt_create(int device, rt_ctx **out) {
     HIP_TRY(hipEventCreate(&c->ev_end));
     HIP_TRY(hipMalloc((void **)&c->counters, sizeof(rt::Counters)));
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(rt::Counters), c->stream));
+    HIP_TRY(hipMalloc((void **)&c->q.ctl, sizeof(rt::QueueCtl) * (rt::RT_MAX_BOUNCES + 2)));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    // persistent traversal kernel: one 64-lane workgroup per wave slot (32 per CU)
+    c->extend_waves = (uint32_t)prop.multiProcessorCount * 32u;
+    // experiment knobs (defaults are the tuned values)
+    if (const char *e = getenv("RT_PIPELINE")) c->pipeline = (strcmp(e, "mega") == 0) ? 0 : 1;
+    if (const char *e = getenv("RT_REFILL")) c->refill_threshold = (uint32_t)atoi(e);
+    if (const char *e = getenv("RT_EXTEND_WAVES")) c->extend_waves = (uint32_t)atoi(e);
+    if (c->refill_threshold < 1u) c->refill_threshold = 1u;
+    if (c->refill_threshold > 64u) c->refill_threshold = 64u;
+    if (c->extend_waves < 1u) c->extend_waves = 1u;
     if (int rc = alloc_images(c)) return rc;
     *out = c;
     return 0;
@@ -221,7 +256,9 @@ int rt_destroy(rt_ctx *c) {
         if (b->raw) hipFree(b->raw);
         if (b->packed) hipFree(b->packed);
     }
-    for (void *p : {(void *)c->sample, (void *)c->acc, (void *)c->sum, (void *)c->aux, (void *)c->counters})
+    for (void *p : {(void *)c->sample, (void *)c->acc, (void *)c->sum, (void *)c->aux, (void *)c->counters,
+                    (void *)c->q.rays[0], (void *)c->q.rays[1], (void *)c->q.hits, (void *)c->q.paths,
+                    (void *)c->q.ctl})
         if (p) hipFree(p);
     for (hipEvent_t e : c->ev_trace) hipEventDestroy(e);
     hipEventDestroy(c->ev_begin);
@@ -298,7 +335,7 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounces, 
     for (uint32_t i = 0; i < nframes; i++) {
         p.time = (float)(first_frame + i);  // renderer.py:211 float(self._frames)
         if (int rc = trace_event(c)) return rc;
-        rt::launch_trace(p, 0, aux, stats, c->stream);
+        trace_frame(c, p, 0, aux, stats);
         if (int rc = trace_event(c)) return rc;
         rt::launch_accumulate(c->sample, c->acc, npix, (float)c->rendered_frames, c->stream);
         c->rendered_frames++;
@@ -404,7 +441,7 @@ int rt_render_sum(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounc
     for (uint32_t i = frame_phase; i < nframes; i += frame_stride) {
         p.time = (float)(first_frame + i);
         if (int rc = trace_event(c)) return rc;
-        rt::launch_trace(p, 1, false, false, c->stream);
+        trace_frame(c, p, 1, false, false);
         if (int rc = trace_event(c)) return rc;
     }
     HIP_TRY(hipGetLastError());

@@ -56,6 +56,20 @@ struct TraceParams {
     uint32_t tiles_x, tiles_y, ntiles;  // 16x16 pixel tiles
 };
 
+// ---- wavefront pipeline: ray queues in device memory ---------------------------------------
+constexpr int RT_MAX_BOUNCES = 66;  // a path never survives bounce index 64 (compute.glsl:430-433)
+struct QueueCtl {
+    uint32_t count;  // rays in this bounce's queue (appended by the previous stage)
+    uint32_t head;   // next unclaimed ray (advanced by the traversal kernel)
+    uint32_t pad[2];
+};
+struct WaveQueues {
+    float4 *rays[2];  // ping-pong ray records, 2 x float4 per ray
+    float2 *hits;     // per ray of the current queue: distance, primitive metadata word
+    float4 *paths;    // per pixel: 2 x float4 (throughput+rng, light+ior)
+    QueueCtl *ctl;    // RT_MAX_BOUNCES + 2 entries
+};
+
 // repack kernels: reference byte layouts -> device records (n elements + 1 zero-source sentinel)
 void launch_repack_nodes(const uint32_t *src, uint32_t n, const float smin[3], const float sext[3], float4 *dst,
                          hipStream_t s);
@@ -66,6 +80,9 @@ void launch_copy_raw32(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t
 
 // mode 0 = reference frame (writes sample), mode 1 = add linear radiance into sum
 void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s);
+// one frame through the wavefront pipeline: generate, then per bounce extend + shade
+void launch_wavefront_frame(const TraceParams &p, const WaveQueues &q, int mode, bool aux, bool stats,
+                            uint32_t extend_waves, uint32_t refill_threshold, hipStream_t s);
 // accumulate pass: acc = srgb(lin(acc) + (lin(sample) - lin(acc)) / (frames + 1))
 void launch_accumulate(const float4 *sample, float4 *acc, size_t npixels, float frames, hipStream_t s);
 // acc = srgb(sum / spp)

@@ -14,7 +14,25 @@
 namespace rt {
 
 #define RT_BLOCK 256
-#define RT_STACK 48  // entries per lane; the reference's own array has 32 and no overflow guard
+// Traversal stack: the first RT_STACK_LDS entries of every lane live in LDS (lane-contiguous, so
+// conflict-free); deeper entries spill to per-lane private memory.  The reference's own array
+// has 32 entries and no overflow guard; here pushes beyond RT_STACK_LDS + RT_STACK_SPILL are
+// dropped and counted.
+#ifndef RT_STACK_LDS
+#define RT_STACK_LDS 20
+#endif
+#ifndef RT_STACK_SPILL
+#define RT_STACK_SPILL 44
+#endif
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 5  // megakernel: waves per SIMD the register allocator must leave room for
+#endif
+#ifndef RT_EXT_STACK_LDS
+#define RT_EXT_STACK_LDS 16  // traversal kernel of the wavefront pipeline: 4 KB of LDS per wavefront
+#endif
+#ifndef RT_EXTEND_MIN_WAVES
+#define RT_EXTEND_MIN_WAVES 8
+#endif
 
 // ------------------------------------------------------------------------------------------
 // scalar helpers
@@ -333,54 +351,54 @@ __device__ __forceinline__ bool box_distance(v3 O, v3 D, v3 b0, v3 b1, float &t_
         va = tv_;                      \
     }
 
-// Returns the distance of the best hit (1e38 if none) and the metadata word of the primitive
-// that produced it.  `stack` points at this lane's column of the LDS stack (stride RT_BLOCK).
-template <bool STATS>
-__device__ __forceinline__ float traverse(const DevScene &sc, v3 O, v3 D, v3 ID, uint32_t &best_code,
-                                          uint32_t *stack, LaneStats &st) {
-    float best = 1e38f;
-    best_code = 0xFFFFFFFFu;
-    int sp = 0;
-    stack[0] = 0u;
-    sp = 1;
-    while (sp > 0) {
-        if (STATS) {
-            st.max_sp = max(st.max_sp, (uint32_t)sp);
-            st.nodes++;
-        }
-        uint32_t ni = stack[(--sp) * RT_BLOCK];
-        ni = min(ni, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
-        const float4 *np = sc.nodes + (size_t)ni * kNodeVec;
-        float4 lox = np[0], hix = np[1], loy = np[2], hiy = np[3], loz = np[4], hiz = np[5], mt = np[6];
-        float k0, k1, k2, k3;
-        bool v0, v1, v2, v3_;
-        // compute.glsl:186-208, one child per macro expansion
-#define SLAB(c, KEY, VAL)                                                           \
-    {                                                                               \
-        float t1x = (lox.c - O.x) * ID.x, t2x = (hix.c - O.x) * ID.x;               \
-        float t1y = (loy.c - O.y) * ID.y, t2y = (hiy.c - O.y) * ID.y;               \
-        float t1z = (loz.c - O.z) * ID.z, t2z = (hiz.c - O.z) * ID.z;               \
-        float tN = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f)); \
-        float tF = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z)); \
-        KEY = tN;                                                                   \
-        VAL = (tN <= tF) && (tN < best);                                            \
+// One iteration of the reference's `while (stackPtr > 0)` loop: pop a node, slab-test its four
+// child boxes, sort, visit far to near (leaves are intersected at once, inner children pushed).
+// `stack` is this lane's column of the LDS stack (element stride STRIDE), `spill` its private
+// overflow array.  best/best_code: distance and metadata word of the best hit so far.
+template <bool STATS, int STRIDE, int LDS_DEPTH>
+__device__ __forceinline__ void node_step(const DevScene &sc, v3 O, v3 D, v3 ID, float &best, uint32_t &best_code,
+                                          int &sp, uint32_t *stack, uint32_t *spill, LaneStats &st) {
+    if (STATS) {
+        st.max_sp = max(st.max_sp, (uint32_t)sp);
+        st.nodes++;
     }
-        SLAB(x, k0, v0) SLAB(y, k1, v1) SLAB(z, k2, v2) SLAB(w, k3, v3_)
+    --sp;
+    uint32_t ni = (sp < LDS_DEPTH) ? stack[sp * STRIDE] : spill[sp - LDS_DEPTH];
+    ni = min(ni, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
+    const float4 *np = sc.nodes + (size_t)ni * kNodeVec;
+    float4 lox = np[0], hix = np[1], loy = np[2], hiy = np[3], loz = np[4], hiz = np[5], mt = np[6];
+    float k0, k1, k2, k3;
+    bool v0, v1, v2, v3_;
+    // compute.glsl:186-208, one child per macro expansion
+#define SLAB(c, KEY, VAL)                                                                        \
+    {                                                                                            \
+        float t1x = (lox.c - O.x) * ID.x, t2x = (hix.c - O.x) * ID.x;                            \
+        float t1y = (loy.c - O.y) * ID.y, t2y = (hiy.c - O.y) * ID.y;                            \
+        float t1z = (loz.c - O.z) * ID.z, t2z = (hiz.c - O.z) * ID.z;                            \
+        float tN = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f)); \
+        float tF = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));              \
+        KEY = tN;                                                                                \
+        VAL = (tN <= tF) && (tN < best);                                                         \
+    }
+    SLAB(x, k0, v0) SLAB(y, k1, v1) SLAB(z, k2, v2) SLAB(w, k3, v3_)
 #undef SLAB
-        uint32_t m0 = f2u(mt.x), m1 = f2u(mt.y), m2 = f2u(mt.z), m3 = f2u(mt.w);
-        // compute.glsl:210-223
-        CSWAP(k0, k1, m0, m1, v0, v1)
-        CSWAP(k2, k3, m2, m3, v2, v3_)
-        CSWAP(k0, k2, m0, m2, v0, v2)
-        CSWAP(k1, k3, m1, m3, v1, v3_)
-        CSWAP(k1, k2, m1, m2, v1, v2)
-        // compute.glsl:290-326: far to near
+    uint32_t m0 = f2u(mt.x), m1 = f2u(mt.y), m2 = f2u(mt.z), m3 = f2u(mt.w);
+    // compute.glsl:210-223
+    CSWAP(k0, k1, m0, m1, v0, v1)
+    CSWAP(k2, k3, m2, m3, v2, v3_)
+    CSWAP(k0, k2, m0, m2, v0, v2)
+    CSWAP(k1, k3, m1, m3, v1, v3_)
+    CSWAP(k1, k2, m1, m2, v1, v2)
+    // compute.glsl:290-326: far to near
 #define VISIT(VAL, META)                                                                          \
     if (VAL) {                                                                                    \
         uint32_t type = META >> 30, idx = META & 0x3FFFFFFFu;                                     \
         if (type == 3u) {                                                                         \
-            if (sp < RT_STACK) {                                                                  \
-                stack[sp * RT_BLOCK] = idx;                                                       \
+            if (sp < LDS_DEPTH) {                                                                 \
+                stack[sp * STRIDE] = idx;                                                         \
+                sp++;                                                                             \
+            } else if (sp < LDS_DEPTH + RT_STACK_SPILL) {                                         \
+                spill[sp - LDS_DEPTH] = idx;                                                      \
                 sp++;                                                                             \
             } else {                                                                              \
                 st.overflow++;                                                                    \
@@ -408,10 +426,8 @@ __device__ __forceinline__ float traverse(const DevScene &sc, v3 O, v3 D, v3 ID,
             }                                                                                     \
         }                                                                                         \
     }
-        VISIT(v3_, m3) VISIT(v2, m2) VISIT(v1, m1) VISIT(v0, m0)
+    VISIT(v3_, m3) VISIT(v2, m2) VISIT(v1, m1) VISIT(v0, m0)
 #undef VISIT
-    }
-    return best;
 }
 
 // Surface attributes of the accepted primitive, derived from (O, D, t, code) exactly as the
@@ -488,8 +504,136 @@ __device__ __forceinline__ v3 ggx_half_vector(v3 n, float a2, float g1, float g2
 }
 
 // ------------------------------------------------------------------------------------------
-// the path-tracing kernel: one lane = one pixel-sample (compute.glsl:451-688)
+// per-path state and the two halves of main() that do not traverse: ray generation
+// (compute.glsl:459-494) and the bounce body after the hit is known (:500-664)
 // ------------------------------------------------------------------------------------------
+struct Path {
+    v3 O, D;
+    v3 thr, light;
+    uint32_t rng;
+    float ior;
+};
+
+__device__ __forceinline__ void primary_ray(const DevScene &sc, int W, int H, int x, int y, float time, Path &ps) {
+    float px = (float)(2 * x - W) / (float)W;
+    float py = (float)(2 * y - H) / (float)H;
+    uint32_t state = ((uint32_t)x * 1973u + (uint32_t)y * 9277u + (uint32_t)(time * 1000.0f) * 26699u) | 1u;
+    float jx = draw(state) - 0.5f;
+    float jy = draw(state) - 0.5f;
+    float qx = px + jx / (float)W;
+    float qy = py + jy / (float)H;
+    const float *M = sc.inv_vp;
+    float far4[4], near4[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        far4[r] = ((M[r] * qx + M[4 + r] * qy) + M[8 + r] * 1.0f) + M[12 + r] * 1.0f;
+        near4[r] = ((M[r] * qx + M[4 + r] * qy) + M[8 + r] * 0.0f) + M[12 + r] * 1.0f;
+    }
+    v3 farp = V(far4[0] / far4[3], far4[1] / far4[3], far4[2] / far4[3]);
+    v3 nearp = V(near4[0] / near4[3], near4[1] / near4[3], near4[2] / near4[3]);
+    ps.D = normalize(farp - nearp);
+    ps.O = V(sc.eye[0], sc.eye[1], sc.eye[2]);
+    ps.thr = V(1.f, 1.f, 1.f);
+    ps.light = V(0.f, 0.f, 0.f);
+    ps.rng = state;
+    ps.ior = 1.0f;
+}
+
+// The body of one loop iteration after `hit = calculate_ray_bvh(ray)`.  tb/code: result of the
+// BVH traversal.  Returns false when the path ends here (miss, or Russian roulette).  `exists`
+// and `thit` report the hit the iteration saw (for the parity record).
+template <bool STATS>
+__device__ __forceinline__ bool bounce(const DevScene &sc, Path &ps, float tb, uint32_t code, uint32_t i,
+                                       bool &exists, float &thit, LaneStats &st) {
+    v3 O = ps.O, D = ps.D;
+    // compute.glsl:332-351: the BVH hit wins only if nearer than the nearest plane hit
+    bool p_exists;
+    float tp;
+    v3 pos, n;
+    uint32_t mat;
+    planes_nearest(sc, O, D, p_exists, tp, pos, n, mat);
+    if (tb < tp) {
+        exists = true;  // best < 9999999 implies a primitive was accepted
+        thit = tb;
+        hit_attributes(sc, O, D, tb, code, pos, n, mat);
+    } else {
+        exists = p_exists;
+        thit = tp;
+    }
+    if (!exists) return false;
+    if (STATS) st.hits++;
+    const float4 *mp = sc.mats + (size_t)min(mat, sc.n_mats) * kMatVec;
+    float4 q0 = mp[0], q1 = mp[1], q2 = mp[2], q3 = mp[3];
+    float smooth = q0.w, trans = q1.w, f0 = q2.w, ior = q3.x, a2 = q3.y;
+    ps.light = ps.light + V(q0.x, q0.y, q0.z) * ps.thr;
+    float cosT = fminf(dot(-D, n), 1.0f);
+    float R = f0 + (1.0f - f0) * d_pow(1.0f - cosT, 5.0f);
+    v3 Dn;
+    if (draw(ps.rng) < R) {
+        if (smooth == 1.0f) {
+            Dn = reflect(D, n);
+        } else {
+            float g1 = draw(ps.rng), g2 = draw(ps.rng);
+            v3 Hh = ggx_half_vector(n, a2, g1, g2);
+            Dn = reflect(D, Hh);
+        }
+        ps.O = pos + Dn * 0.0001f;
+        ps.thr = ps.thr * V(q1.x, q1.y, q1.z);
+    } else if (draw(ps.rng) < trans) {
+        bool entering = dot(D, n) < 0.0f;
+        v3 nn = entering ? n : -n;
+        float n1 = ps.ior, n2 = entering ? ior : 1.0f;
+        float g1 = draw(ps.rng), g2 = draw(ps.rng);
+        v3 Hh = ggx_half_vector(n, a2, g1, g2);
+        float eta = n1 / n2;
+        float dn = dot(Hh, D);
+        float k = 1.0f - eta * (eta * (1.0f - dn * dn));  // association of the GLSL built-in
+        v3 r = V(0.f, 0.f, 0.f);
+        if (!(k < 0.0f)) r = D * eta - Hh * (eta * dn + sqrtf(k));
+        if (dot(r, r) == 0.0f) {
+            Dn = reflect(D, nn);
+        } else {
+            Dn = r;
+            ps.ior = n2;
+        }
+        ps.O = pos + Dn * 0.0001f;
+    } else {
+        float u1 = draw(ps.rng), u2 = draw(ps.rng);
+        float rr = sqrtf(u2);
+        float th = (2.0f * 3.14159265f) * u1;
+        float sn, cs;
+        d_sincos(th, sn, cs);
+        float sx = rr * cs, sy = rr * sn, sz = sqrtf(fmaxf(0.0f, 1.0f - u2));
+        v3 tg;
+        if (fabsf(n.x) > fabsf(n.y)) {
+            v3 t0 = V(n.z, 0.0f, -n.x);
+            tg = t0 / sqrtf(dot(t0, t0));
+        } else {
+            v3 t0 = V(0.0f, -n.z, n.y);
+            tg = t0 / sqrtf(dot(t0, t0));
+        }
+        v3 bt = cross(n, tg);
+        v3 dif = (tg * sx + bt * sy) + n * sz;
+        float dDn = dot(D, n);
+        v3 spec = normalize(D - (n * 2.0f) * dDn);
+        ps.O = pos + n * 0.0001f;
+        Dn = V(dif.x + smooth * (spec.x - dif.x), dif.y + smooth * (spec.y - dif.y),
+               dif.z + smooth * (spec.z - dif.z));
+        if (dot(Dn, n) < 0.0f) Dn = -Dn;
+        ps.thr = ps.thr * V(q2.x, q2.y, q2.z);
+    }
+    ps.D = Dn;
+    // compute.glsl:428-445
+    if (i >= 3u) {
+        if (i >= 64u) return false;
+        float lum = dot(ps.thr, V(0.2126f, 0.7152f, 0.0722f));
+        float pr = fminf(fmaxf(lum, 0.05f), 0.95f);
+        if (draw(ps.rng) > pr) return false;
+        ps.thr = ps.thr / pr;
+    }
+    return true;
+}
+
 __device__ __forceinline__ uint32_t morton2(uint32_t x, uint32_t y) {
     auto part = [](uint32_t v) {
         v &= 0xFFFFu;
@@ -502,200 +646,125 @@ __device__ __forceinline__ uint32_t morton2(uint32_t x, uint32_t y) {
     return part(x) | (part(y) << 1);
 }
 
-template <int MODE, bool AUX, bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void trace_kernel(TraceParams p) {
-    __shared__ uint32_t lds_stack[RT_STACK * RT_BLOCK];
-    const DevScene &sc = p.scene;
-    // 16x16 pixel tile per workgroup, 8x8 per wavefront.  Workgroups that share an XCD (equal
-    // blockIdx % 8 under round-robin placement) get a contiguous run of tiles so that their
-    // node working sets overlap in that XCD's L2.
-    uint32_t b = blockIdx.x;
-    uint32_t per = (p.ntiles + 7u) / 8u;
-    uint32_t tile = (b & 7u) * per + (b >> 3);
-    if (tile >= p.ntiles) return;
-    uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    int x = (int)(tx * 16u + (wave & 1u) * 8u + (lane & 7u));
-    int y = (int)(ty * 16u + (wave >> 1) * 8u + (lane >> 3));
-    bool live = (x < p.WW) && (y < p.HH);
-    if (MODE == 1 && p.nshards > 1u) {
-        // 64x64 pixel macro tiles dealt round-robin in Morton order
-        uint32_t owner = morton2((uint32_t)x >> 6, (uint32_t)y >> 6) % p.nshards;
-        live = live && (owner == p.shard);
-    }
-    uint32_t *stack = lds_stack + threadIdx.x;
-    LaneStats st = {0, 0, 0, 0, 0, 0, 0};
-    uint32_t nrays = 0;
-    if (live) {
-        const int W = p.W, H = p.H;
-        float px = (float)(2 * x - W) / (float)W;
-        float py = (float)(2 * y - H) / (float)H;
-        uint32_t state = ((uint32_t)x * 1973u + (uint32_t)y * 9277u + (uint32_t)(p.time * 1000.0f) * 26699u) | 1u;
-        float jx = draw(state) - 0.5f;
-        float jy = draw(state) - 0.5f;
-        float qx = px + jx / (float)W;
-        float qy = py + jy / (float)H;
-        const float *M = sc.inv_vp;
-        float far4[4], near4[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            far4[r] = ((M[r] * qx + M[4 + r] * qy) + M[8 + r] * 1.0f) + M[12 + r] * 1.0f;
-            near4[r] = ((M[r] * qx + M[4 + r] * qy) + M[8 + r] * 0.0f) + M[12 + r] * 1.0f;
-        }
-        v3 farp = V(far4[0] / far4[3], far4[1] / far4[3], far4[2] / far4[3]);
-        v3 nearp = V(near4[0] / near4[3], near4[1] / near4[3], near4[2] / near4[3]);
-        v3 D = normalize(farp - nearp);
-        v3 O = V(sc.eye[0], sc.eye[1], sc.eye[2]);
-        v3 ID = V(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
-        float ray_ior = 1.0f;
-        v3 thr = V(1.f, 1.f, 1.f), light = V(0.f, 0.f, 0.f);
-        const uint32_t nb = (uint32_t)p.bounces;
-        uint32_t aux0 = 0xFFFFFFFFu, aux1 = 0u, aux2 = 0u;
-        for (uint32_t i = 0; i < nb; i++) {
-            uint32_t code;
-            float tb = traverse<STATS>(sc, O, D, ID, code, stack, st);
-            nrays++;
-            // compute.glsl:332-351: the BVH hit wins only if nearer than the nearest plane hit
-            bool p_exists;
-            float tp;
-            v3 ppos, pn;
-            uint32_t pmat;
-            planes_nearest(sc, O, D, p_exists, tp, ppos, pn, pmat);
-            bool exists;
-            v3 pos, n;
-            uint32_t mat;
-            float thit;
-            if (tb < tp) {
-                exists = true;  // best < 9999999 implies a primitive was accepted
-                thit = tb;
-                hit_attributes(sc, O, D, tb, code, pos, n, mat);
-            } else {
-                exists = p_exists;
-                thit = tp;
-                pos = ppos;
-                n = pn;
-                mat = pmat;
-            }
-            if (AUX && i == 0) {
-                aux0 = code;
-                aux1 = f2u(thit);
-                aux2 = exists ? 1u : 0u;
-            }
-            if (!exists) break;
-            if (STATS) st.hits++;
-            const float4 *mp = sc.mats + (size_t)min(mat, sc.n_mats) * kMatVec;
-            float4 q0 = mp[0], q1 = mp[1], q2 = mp[2], q3 = mp[3];
-            float smooth = q0.w, trans = q1.w, f0 = q2.w, ior = q3.x, a2 = q3.y;
-            light = light + V(q0.x, q0.y, q0.z) * thr;
-            float cosT = fminf(dot(-D, n), 1.0f);
-            float R = f0 + (1.0f - f0) * d_pow(1.0f - cosT, 5.0f);
-            v3 Dn;
-            if (draw(state) < R) {
-                if (smooth == 1.0f) {
-                    Dn = reflect(D, n);
-                } else {
-                    float g1 = draw(state), g2 = draw(state);
-                    v3 Hh = ggx_half_vector(n, a2, g1, g2);
-                    Dn = reflect(D, Hh);
-                }
-                O = pos + Dn * 0.0001f;
-                thr = thr * V(q1.x, q1.y, q1.z);
-            } else if (draw(state) < trans) {
-                bool entering = dot(D, n) < 0.0f;
-                v3 nn = entering ? n : -n;
-                float n1 = ray_ior, n2 = entering ? ior : 1.0f;
-                float g1 = draw(state), g2 = draw(state);
-                v3 Hh = ggx_half_vector(n, a2, g1, g2);
-                float eta = n1 / n2;
-                float dn = dot(Hh, D);
-                float k = 1.0f - eta * (eta * (1.0f - dn * dn));
-                v3 r = V(0.f, 0.f, 0.f);
-                if (!(k < 0.0f)) r = D * eta - Hh * (eta * dn + sqrtf(k));
-                if (dot(r, r) == 0.0f) {
-                    Dn = reflect(D, nn);
-                } else {
-                    Dn = r;
-                    ray_ior = n2;
-                }
-                O = pos + Dn * 0.0001f;
-            } else {
-                float u1 = draw(state), u2 = draw(state);
-                float rr = sqrtf(u2);
-                float th = (2.0f * 3.14159265f) * u1;
-                float sn, cs;
-                d_sincos(th, sn, cs);
-                float sx = rr * cs, sy = rr * sn, sz = sqrtf(fmaxf(0.0f, 1.0f - u2));
-                v3 tg;
-                if (fabsf(n.x) > fabsf(n.y)) {
-                    v3 t0 = V(n.z, 0.0f, -n.x);
-                    tg = t0 / sqrtf(dot(t0, t0));
-                } else {
-                    v3 t0 = V(0.0f, -n.z, n.y);
-                    tg = t0 / sqrtf(dot(t0, t0));
-                }
-                v3 bt = cross(n, tg);
-                v3 dif = (tg * sx + bt * sy) + n * sz;
-                float dDn = dot(D, n);
-                v3 spec = normalize(D - (n * 2.0f) * dDn);
-                O = pos + n * 0.0001f;
-                Dn = V(dif.x + smooth * (spec.x - dif.x), dif.y + smooth * (spec.y - dif.y),
-                       dif.z + smooth * (spec.z - dif.z));
-                if (dot(Dn, n) < 0.0f) Dn = -Dn;
-                thr = thr * V(q2.x, q2.y, q2.z);
-            }
-            D = Dn;
-            ID = V(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
-            // compute.glsl:428-445
-            if (i >= 3u) {
-                if (i >= 64u) break;
-                float lum = dot(thr, V(0.2126f, 0.7152f, 0.0722f));
-                float pr = fminf(fmaxf(lum, 0.05f), 0.95f);
-                if (draw(state) > pr) break;
-                thr = thr / pr;
-            }
-        }
-        size_t pix = (size_t)y * W + x;
-        if (MODE == 0) {
-            if (p.sample) p.sample[pix] = make_float4(l2s(light.x), l2s(light.y), l2s(light.z), 1.0f);
-        } else {
-            float4 s = p.sum[pix];
-            p.sum[pix] = make_float4(s.x + light.x, s.y + light.y, s.z + light.z, s.w + 1.0f);
-        }
-        if (AUX) {
-            uint4 *a = reinterpret_cast<uint4 *>(p.aux + pix * 16);
-            a[0] = make_uint4(aux0, aux1, aux2, st.nodes);
-            a[1] = make_uint4(f2u(D.x), f2u(D.y), f2u(D.z), f2u(O.x));
-            a[2] = make_uint4(f2u(O.y), f2u(O.z), f2u(thr.x), f2u(thr.y));
-            a[3] = make_uint4(f2u(thr.z), state, nrays, f2u(ray_ior));
-        }
-    }
-    // counters: one atomic per wavefront per counter
-    auto wave_sum = [](uint32_t v) {
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        return v;
-    };
-    auto wave_max = [](uint32_t v) {
-        for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o));
-        return v;
-    };
-    uint32_t r = wave_sum(nrays), ps = wave_sum(live ? 1u : 0u), ov = wave_sum(st.overflow);
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o));
+    return v;
+}
+
+// one atomic per wavefront per counter
+template <bool STATS>
+__device__ __forceinline__ void flush_counters(Counters *c, uint32_t lane, uint32_t nrays, uint32_t nsamples,
+                                               const LaneStats &st) {
+    uint32_t r = wave_sum(nrays), ps = wave_sum(nsamples), ov = wave_sum(st.overflow);
     if (lane == 0) {
-        if (r) atomicAdd(&p.counters->rays, (unsigned long long)r);
-        if (ps) atomicAdd(&p.counters->pixel_samples, (unsigned long long)ps);
-        if (ov) atomicAdd(&p.counters->stack_overflows, (unsigned long long)ov);
+        if (r) atomicAdd(&c->rays, (unsigned long long)r);
+        if (ps) atomicAdd(&c->pixel_samples, (unsigned long long)ps);
+        if (ov) atomicAdd(&c->stack_overflows, (unsigned long long)ov);
     }
     if (STATS) {
         uint32_t a = wave_sum(st.nodes), t3 = wave_sum(st.tri), s3 = wave_sum(st.sph), b3 = wave_sum(st.box),
                  m = wave_max(st.max_sp), h3 = wave_sum(st.hits);
         if (lane == 0) {
-            atomicAdd(&p.counters->nodes, (unsigned long long)a);
-            atomicAdd(&p.counters->tri_tests, (unsigned long long)t3);
-            atomicAdd(&p.counters->sphere_tests, (unsigned long long)s3);
-            atomicAdd(&p.counters->box_tests, (unsigned long long)b3);
-            atomicMax(&p.counters->max_stack, (unsigned long long)m);
-            atomicAdd(&p.counters->hits, (unsigned long long)h3);
+            atomicAdd(&c->nodes, (unsigned long long)a);
+            atomicAdd(&c->tri_tests, (unsigned long long)t3);
+            atomicAdd(&c->sphere_tests, (unsigned long long)s3);
+            atomicAdd(&c->box_tests, (unsigned long long)b3);
+            atomicMax(&c->max_stack, (unsigned long long)m);
+            atomicAdd(&c->hits, (unsigned long long)h3);
         }
     }
+}
+
+// tile -> pixel mapping shared by the megakernel and the ray generator: 16x16 pixel tile per
+// workgroup, 8x8 per wavefront.  Workgroups that share an XCD (equal blockIdx % 8 under
+// round-robin placement) get a contiguous run of tiles so that their node working sets overlap
+// in that XCD's L2.  Returns false for surplus workgroups and uncovered / unowned pixels.
+__device__ __forceinline__ bool tile_pixel(const TraceParams &p, bool sharded, int &x, int &y) {
+    uint32_t b = blockIdx.x;
+    uint32_t per = (p.ntiles + 7u) / 8u;
+    uint32_t tile = (b & 7u) * per + (b >> 3);
+    if (tile >= p.ntiles) return false;
+    uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    x = (int)(tx * 16u + (wave & 1u) * 8u + (lane & 7u));
+    y = (int)(ty * 16u + (wave >> 1) * 8u + (lane >> 3));
+    bool live = (x < p.WW) && (y < p.HH);
+    if (sharded && p.nshards > 1u) {
+        // 64x64 pixel macro tiles dealt round-robin in Morton order
+        uint32_t owner = morton2((uint32_t)x >> 6, (uint32_t)y >> 6) % p.nshards;
+        live = live && (owner == p.shard);
+    }
+    return live;
+}
+
+// writes a finished pixel-sample: MODE 0 the sRGB-encoded sample image (compute.glsl:673),
+// MODE 1 adds the linear radiance into the sum image
+template <int MODE>
+__device__ __forceinline__ void write_pixel(const TraceParams &p, size_t pix, v3 light) {
+    if (MODE == 0) {
+        if (p.sample) p.sample[pix] = make_float4(l2s(light.x), l2s(light.y), l2s(light.z), 1.0f);
+    } else {
+        float4 s = p.sum[pix];
+        p.sum[pix] = make_float4(s.x + light.x, s.y + light.y, s.z + light.z, s.w + 1.0f);
+    }
+}
+
+__device__ __forceinline__ void write_aux_tail(uint32_t *aux, size_t pix, const Path &ps, uint32_t nrays) {
+    uint4 *a = reinterpret_cast<uint4 *>(aux + pix * 16);
+    a[1] = make_uint4(f2u(ps.D.x), f2u(ps.D.y), f2u(ps.D.z), f2u(ps.O.x));
+    a[2] = make_uint4(f2u(ps.O.y), f2u(ps.O.z), f2u(ps.thr.x), f2u(ps.thr.y));
+    a[3] = make_uint4(f2u(ps.thr.z), ps.rng, nrays, f2u(ps.ior));
+}
+
+// ------------------------------------------------------------------------------------------
+// pipeline A — megakernel: one lane = one pixel-sample, the whole of main() (compute.glsl:451-688)
+// ------------------------------------------------------------------------------------------
+template <int MODE, bool AUX, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(TraceParams p) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    uint32_t spill[RT_STACK_SPILL];
+    const DevScene &sc = p.scene;
+    int x, y;
+    bool live = tile_pixel(p, MODE == 1, x, y);
+    uint32_t lane = threadIdx.x & 63u;
+    uint32_t *stack = lds_stack + threadIdx.x;
+    LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t nrays = 0;
+    if (live) {
+        Path ps;
+        primary_ray(sc, p.W, p.H, x, y, p.time, ps);
+        const uint32_t nb = (uint32_t)p.bounces;
+        uint32_t aux0 = 0xFFFFFFFFu, aux1 = 0u, aux2 = 0u;
+        for (uint32_t i = 0; i < nb; i++) {
+            v3 ID = V(1.0f / ps.D.x, 1.0f / ps.D.y, 1.0f / ps.D.z);
+            float best = 1e38f;
+            uint32_t code = 0xFFFFFFFFu;
+            int sp = 1;
+            stack[0] = 0u;
+            while (sp > 0) node_step<STATS, RT_BLOCK, RT_STACK_LDS>(sc, ps.O, ps.D, ID, best, code, sp, stack, spill, st);
+            nrays++;
+            bool exists;
+            float thit;
+            bool alive = bounce<STATS>(sc, ps, best, code, i, exists, thit, st);
+            if (AUX && i == 0) {
+                aux0 = code;
+                aux1 = f2u(thit);
+                aux2 = exists ? 1u : 0u;
+            }
+            if (!alive) break;
+        }
+        size_t pix = (size_t)y * p.W + x;
+        write_pixel<MODE>(p, pix, ps.light);
+        if (AUX) {
+            reinterpret_cast<uint4 *>(p.aux + pix * 16)[0] = make_uint4(aux0, aux1, aux2, st.nodes);
+            write_aux_tail(p.aux, pix, ps, nrays);
+        }
+    }
+    flush_counters<STATS>(p.counters, lane, nrays, live ? 1u : 0u, st);
 }
 
 void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s) {
@@ -715,6 +784,260 @@ void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStrea
         else L(1, false, false);
     }
 #undef L
+}
+
+// ------------------------------------------------------------------------------------------
+// pipeline B — wavefront: rays live in queues in HBM; per bounce one persistent EXTEND kernel
+// (traversal only, lanes refilled from the queue as they finish) and one SHADE kernel (the rest
+// of the loop body, emits the next bounce's rays compacted).  Same arithmetic per path as the
+// megakernel, only the scheduling differs.
+//   ray record (32 B):   [0] O.xyz, pixel index   [1] D.xyz, bounce-0 marker (unused)
+//   hit record ( 8 B):   distance, metadata word of the primitive
+//   path record (32 B, indexed by pixel): [0] throughput.rgb, rng   [1] light.rgb, ior
+// ------------------------------------------------------------------------------------------
+#define RT_CHUNK 128  // rays a wavefront claims from the queue per atomic
+
+template <int MODE, bool AUX>
+__global__ __launch_bounds__(RT_BLOCK) void generate_kernel(TraceParams p, WaveQueues q) {
+    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_wave_off[RT_BLOCK / 64];
+    const DevScene &sc = p.scene;
+    int x, y;
+    bool live = tile_pixel(p, MODE == 1, x, y);
+    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t nb = (uint32_t)p.bounces;
+    Path ps;
+    size_t pix = 0;
+    if (live) {
+        primary_ray(sc, p.W, p.H, x, y, p.time, ps);
+        pix = (size_t)y * p.W + x;
+        if (AUX) {
+            reinterpret_cast<uint4 *>(p.aux + pix * 16)[0] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+            write_aux_tail(p.aux, pix, ps, 0u);
+        }
+        if (nb == 0u) write_pixel<MODE>(p, pix, ps.light);
+    }
+    bool emit = live && nb > 0u;
+    // block-aggregated append: one atomic per workgroup
+    unsigned long long m = __ballot(emit);
+    uint32_t wcount = (uint32_t)__popcll(m);
+    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (lane == 0) s_wave_off[wave] = wcount;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < RT_BLOCK / 64; w++) {
+            uint32_t c = s_wave_off[w];
+            s_wave_off[w] = tot;
+            tot += c;
+        }
+        s_base = tot ? atomicAdd(&q.ctl[0].count, tot) : 0u;
+    }
+    __syncthreads();
+    if (emit) {
+        uint32_t slot = s_base + s_wave_off[wave] + rank;
+        q.rays[0][(size_t)slot * 2] = make_float4(ps.O.x, ps.O.y, ps.O.z, u2f((uint32_t)pix));
+        q.rays[0][(size_t)slot * 2 + 1] = make_float4(ps.D.x, ps.D.y, ps.D.z, 0.f);
+        q.paths[pix * 2] = make_float4(ps.thr.x, ps.thr.y, ps.thr.z, u2f(ps.rng));
+        q.paths[pix * 2 + 1] = make_float4(ps.light.x, ps.light.y, ps.light.z, ps.ior);
+    }
+    LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+    flush_counters<false>(p.counters, lane, 0u, live ? 1u : 0u, st);
+}
+
+// Persistent traversal kernel.  Each wavefront loops: lanes whose stack is empty retire their
+// result and are refilled from the queue in batches (wave-uniform chunk cursor, one atomic per
+// RT_CHUNK rays); every lane with work performs one node step per iteration.  Terminates when
+// the queue is exhausted and every lane is idle.
+template <bool STATS>
+__global__ __launch_bounds__(64, RT_EXTEND_MIN_WAVES) void extend_kernel(DevScene sc, WaveQueues q, uint32_t bounce_index,
+                                                                        uint32_t refill_threshold, Counters *counters,
+                                                                        uint32_t *aux) {
+    __shared__ uint32_t lds_stack[RT_EXT_STACK_LDS * 64];
+    uint32_t spill[RT_STACK_SPILL];
+    const uint32_t lane = threadIdx.x;
+    uint32_t *stack = lds_stack + lane;
+    const uint32_t qi = bounce_index & 1u;
+    const float4 *__restrict__ rays = q.rays[qi];
+    float2 *__restrict__ hits = q.hits;
+    QueueCtl *ctl = q.ctl + bounce_index;
+    const uint32_t n_rays = __hip_atomic_load(&ctl->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t nrays_done = 0;
+    // wave-uniform chunk cursor
+    uint32_t cur = 0, end = 0;
+    bool exhausted = false;
+    int ray = -1;
+    int sp = 0;
+    v3 O = V(0, 0, 0), D = V(0, 0, 0), ID = V(0, 0, 0);
+    float best = 1e38f;
+    uint32_t code = 0xFFFFFFFFu;
+    uint32_t nodes_this_ray = 0;
+    for (;;) {
+        bool idle = (sp == 0);
+        unsigned long long idle_mask = __ballot(idle);
+        uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if (n_idle >= refill_threshold || n_idle == 64u) {
+            if (idle && ray >= 0) {
+                hits[ray] = make_float2(best, u2f(code));
+                if (STATS && aux) {
+                    uint32_t pix = f2u(rays[(size_t)ray * 2].w);
+                    atomicAdd(aux + (size_t)pix * 16 + 3, nodes_this_ray);
+                }
+                nrays_done++;
+                ray = -1;
+            }
+            if (!exhausted) {
+                // hand the idle lanes consecutive ray indices from the current chunk(s)
+                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                uint32_t given = 0;  // idle lanes served so far (wave-uniform)
+                while (given < n_idle && !exhausted) {
+                    if (cur >= end) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&ctl->head, (uint32_t)RT_CHUNK);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (base >= n_rays) {
+                            exhausted = true;
+                            break;
+                        }
+                        cur = base;
+                        end = min(base + (uint32_t)RT_CHUNK, n_rays);
+                    }
+                    uint32_t take = min(n_idle - given, end - cur);
+                    if (idle && rank >= given && rank < given + take) {
+                        ray = (int)(cur + (rank - given));
+                        float4 r0 = rays[(size_t)ray * 2], r1 = rays[(size_t)ray * 2 + 1];
+                        O = V(r0.x, r0.y, r0.z);
+                        D = V(r1.x, r1.y, r1.z);
+                        ID = V(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+                        best = 1e38f;
+                        code = 0xFFFFFFFFu;
+                        stack[0] = 0u;
+                        sp = 1;
+                        nodes_this_ray = 0;
+                    }
+                    cur += take;
+                    given += take;
+                }
+            }
+            if (exhausted && __ballot(sp > 0) == 0ull) break;
+        }
+        if (sp > 0) {
+            if (STATS) nodes_this_ray++;
+            node_step<STATS, 64, RT_EXT_STACK_LDS>(sc, O, D, ID, best, code, sp, stack, spill, st);
+        }
+    }
+    flush_counters<STATS>(counters, lane, nrays_done, 0u, st);
+}
+
+// The rest of the loop body for every ray of bounce `bounce_index`, one lane per ray.
+template <int MODE, bool AUX, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void shade_kernel(TraceParams p, WaveQueues q, uint32_t bounce_index) {
+    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_wave_off[RT_BLOCK / 64];
+    const DevScene &sc = p.scene;
+    const uint32_t qi = bounce_index & 1u;
+    const uint32_t n_rays = __hip_atomic_load(&q.ctl[bounce_index].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (blockIdx.x * RT_BLOCK >= n_rays) return;  // whole workgroup beyond the queue
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t nb = (uint32_t)p.bounces;
+    LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+    bool live = i < n_rays, alive = false;
+    Path ps;
+    size_t pix = 0;
+    if (live) {
+        float4 r0 = q.rays[qi][(size_t)i * 2], r1 = q.rays[qi][(size_t)i * 2 + 1];
+        float2 h = q.hits[i];
+        pix = f2u(r0.w);
+        float4 s0 = q.paths[pix * 2], s1 = q.paths[pix * 2 + 1];
+        ps.O = V(r0.x, r0.y, r0.z);
+        ps.D = V(r1.x, r1.y, r1.z);
+        ps.thr = V(s0.x, s0.y, s0.z);
+        ps.rng = f2u(s0.w);
+        ps.light = V(s1.x, s1.y, s1.z);
+        ps.ior = s1.w;
+        bool exists;
+        float thit;
+        alive = bounce<STATS>(sc, ps, h.x, f2u(h.y), bounce_index, exists, thit, st);
+        if (AUX && bounce_index == 0u) {
+            uint32_t *a = p.aux + pix * 16;
+            a[0] = f2u(h.y);
+            a[1] = f2u(thit);
+            a[2] = exists ? 1u : 0u;
+        }
+        alive = alive && (bounce_index + 1u < nb);
+        if (!alive) {
+            write_pixel<MODE>(p, pix, ps.light);
+            if (AUX) write_aux_tail(p.aux, pix, ps, bounce_index + 1u);
+        }
+    }
+    // block-aggregated append of the surviving rays to the other queue
+    unsigned long long m = __ballot(alive);
+    uint32_t wcount = (uint32_t)__popcll(m);
+    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (lane == 0) s_wave_off[wave] = wcount;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < RT_BLOCK / 64; w++) {
+            uint32_t c = s_wave_off[w];
+            s_wave_off[w] = tot;
+            tot += c;
+        }
+        s_base = tot ? atomicAdd(&q.ctl[bounce_index + 1u].count, tot) : 0u;
+    }
+    __syncthreads();
+    if (alive) {
+        uint32_t slot = s_base + s_wave_off[wave] + rank;
+        float4 *out = q.rays[qi ^ 1u];
+        out[(size_t)slot * 2] = make_float4(ps.O.x, ps.O.y, ps.O.z, u2f((uint32_t)pix));
+        out[(size_t)slot * 2 + 1] = make_float4(ps.D.x, ps.D.y, ps.D.z, 0.f);
+        q.paths[pix * 2] = make_float4(ps.thr.x, ps.thr.y, ps.thr.z, u2f(ps.rng));
+        q.paths[pix * 2 + 1] = make_float4(ps.light.x, ps.light.y, ps.light.z, ps.ior);
+    }
+    if (STATS) flush_counters<true>(p.counters, lane, 0u, 0u, st);
+}
+
+void launch_wavefront_frame(const TraceParams &p, const WaveQueues &q, int mode, bool aux, bool stats,
+                            uint32_t extend_waves, uint32_t refill_threshold, hipStream_t s) {
+    uint32_t per = (p.ntiles + 7u) / 8u;
+    if (per == 0) return;
+    const uint32_t nb_raw = (uint32_t)p.bounces;
+    const uint32_t nb = nb_raw > 65u ? 65u : nb_raw;  // a path never survives bounce index 64
+    // queue control words (count of every bounce's queue, claim cursor) start at zero
+    hipMemsetAsync(q.ctl, 0, sizeof(QueueCtl) * (RT_MAX_BOUNCES + 2), s);
+    dim3 tgrid(per * 8u), block(RT_BLOCK);
+#define G(M, A) hipLaunchKernelGGL((generate_kernel<M, A>), tgrid, block, 0, s, p, q)
+    if (mode == 0) {
+        if (aux) G(0, true);
+        else G(0, false);
+    } else {
+        G(1, false);
+    }
+#undef G
+    const uint32_t max_rays = (uint32_t)p.WW * (uint32_t)p.HH;
+    dim3 sgrid((max_rays + RT_BLOCK - 1) / RT_BLOCK);
+    for (uint32_t b = 0; b < nb; b++) {
+        if (stats)
+            hipLaunchKernelGGL((extend_kernel<true>), dim3(extend_waves), dim3(64), 0, s, p.scene, q, b,
+                               refill_threshold, p.counters, aux ? p.aux : nullptr);
+        else
+            hipLaunchKernelGGL((extend_kernel<false>), dim3(extend_waves), dim3(64), 0, s, p.scene, q, b,
+                               refill_threshold, p.counters, (uint32_t *)nullptr);
+#define S(M, A, T) hipLaunchKernelGGL((shade_kernel<M, A, T>), sgrid, block, 0, s, p, q, b)
+        if (mode == 0) {
+            if (aux && stats) S(0, true, true);
+            else if (aux) S(0, true, false);
+            else if (stats) S(0, false, true);
+            else S(0, false, false);
+        } else {
+            if (stats) S(1, false, true);
+            else S(1, false, false);
+        }
+#undef S
+    }
 }
 
 // ------------------------------------------------------------------------------------------

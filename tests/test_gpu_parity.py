@@ -24,11 +24,18 @@ def _cases():
     return out
 
 
-@pytest.fixture(scope="module")
-def renderer():
+@pytest.fixture(scope="module", params=["wave", "mega"])
+def renderer(request):
+    """Both schedulings of the same arithmetic: the wavefront pipeline (default) and the megakernel."""
+    import os
+
     from raytracer_amd.renderer import Renderer
 
-    r = Renderer(device=0, singleton=False)
+    os.environ["RT_PIPELINE"] = request.param
+    try:
+        r = Renderer(device=0, singleton=False)
+    finally:
+        os.environ.pop("RT_PIPELINE", None)
     yield r
     r.close()
 
