@@ -54,11 +54,14 @@ struct rt_ctx {
     std::vector<hipEvent_t> ev_trace;  // pairs around trace kernels of the last call
     size_t ev_trace_used = 0;
     bool timed = false;
-    // scheduling of the frame: 0 = megakernel, 1 = wavefront (ray queues, persistent traversal)
-    int pipeline = 1;
-    rt::WaveQueues q = {{nullptr, nullptr}, nullptr, nullptr, nullptr};
+    // scheduling of the frame: 0 = megakernel (default: measured faster), 1 = wavefront (ray queue
+    // in HBM, persistent traversal kernel); RT_PIPELINE=wave selects the latter
+    int pipeline = 0;
+    rt::WaveQueues q = {{nullptr, nullptr}, nullptr, nullptr};
+    uint64_t pixel_samples = 0;  // pixel-samples queued since the last rt_reset_stats
     uint32_t extend_waves = 8192;
     uint32_t refill_threshold = 16;
+    uint32_t leaf_threshold = 8;
 };
 
 namespace {
@@ -108,15 +111,16 @@ int alloc_images(rt_ctx *c) {
         HIP_TRY(hipFree(c->aux));
         c->aux = nullptr;
     }
-    // ray queues of the wavefront pipeline: at most one ray per pixel per bounce
-    for (void **p : {(void **)&c->q.rays[0], (void **)&c->q.rays[1], (void **)&c->q.hits, (void **)&c->q.paths}) {
+    // ray queue of the wavefront pipeline: one slot per lane of the 16x16 tile grid
+    for (void **p : {(void **)&c->q.rays[0], (void **)&c->q.hits, (void **)&c->q.paths}) {
         if (*p) HIP_TRY(hipFree(*p));
         *p = nullptr;
     }
-    HIP_TRY(hipMalloc((void **)&c->q.rays[0], n * 2 * sizeof(float4)));
-    HIP_TRY(hipMalloc((void **)&c->q.rays[1], n * 2 * sizeof(float4)));
-    HIP_TRY(hipMalloc((void **)&c->q.hits, n * sizeof(float2)));
-    HIP_TRY(hipMalloc((void **)&c->q.paths, n * 2 * sizeof(float4)));
+    size_t tiles = (size_t)((c->W / 8 * 8 + 15) / 16) * (size_t)((c->H / 4 * 4 + 15) / 16);
+    size_t slots = ((tiles + 7) / 8) * 8 * 256 + 256;
+    HIP_TRY(hipMalloc((void **)&c->q.rays[0], slots * 2 * sizeof(float4)));
+    HIP_TRY(hipMalloc((void **)&c->q.hits, slots * sizeof(float2)));
+    HIP_TRY(hipMalloc((void **)&c->q.paths, slots * 2 * sizeof(float4)));
     c->rendered_frames = 0;
     return 0;
 }
@@ -126,7 +130,7 @@ void trace_frame(rt_ctx *c, const rt::TraceParams &p, int mode, bool aux, bool s
     if (c->pipeline == 0)
         rt::launch_trace(p, mode, aux, stats, c->stream);
     else
-        rt::launch_wavefront_frame(p, c->q, mode, aux, stats, c->extend_waves, c->refill_threshold, c->stream);
+        rt::launch_wavefront_frame(p, c->q, mode, aux, stats, c->extend_waves, c->refill_threshold, c->leaf_threshold, c->stream);
 }
 
 // brings the device records of one binding up to date
@@ -170,6 +174,8 @@ int prepare_scene(rt_ctx *c, rt::DevScene *s) {
     s->n_mats = c->mats.count;
     memcpy(s->inv_vp, c->inv_vp, sizeof s->inv_vp);
     memcpy(s->eye, c->eye, sizeof s->eye);
+    memcpy(s->smin, c->smin, sizeof s->smin);
+    memcpy(s->sext, c->sext, sizeof s->sext);
     return 0;
 }
 
@@ -187,6 +193,31 @@ void fill_params(rt_ctx *c, rt::TraceParams *p) {
     p->tiles_x = (uint32_t)((p->WW + 15) / 16);
     p->tiles_y = (uint32_t)((p->HH + 15) / 16);
     p->ntiles = p->tiles_x * p->tiles_y;
+}
+
+// pixels of the covered area that belong to `shard`: 64x64 macro tiles dealt round-robin in
+// Morton order (the same rule as the kernels' tile_pixel)
+uint32_t morton2(uint32_t x, uint32_t y) {
+    auto part = [](uint32_t v) {
+        v &= 0xFFFFu;
+        v = (v | (v << 8)) & 0x00FF00FFu;
+        v = (v | (v << 4)) & 0x0F0F0F0Fu;
+        v = (v | (v << 2)) & 0x33333333u;
+        v = (v | (v << 1)) & 0x55555555u;
+        return v;
+    };
+    return part(x) | (part(y) << 1);
+}
+uint64_t owned_pixels(int WW, int HH, uint32_t shard, uint32_t nshards) {
+    if (nshards <= 1) return (uint64_t)WW * (uint64_t)HH;
+    uint64_t n = 0;
+    for (int ty = 0; ty * 64 < HH; ty++)
+        for (int tx = 0; tx * 64 < WW; tx++)
+            if (morton2((uint32_t)tx, (uint32_t)ty) % nshards == shard) {
+                int w = WW - tx * 64 < 64 ? WW - tx * 64 : 64, h = HH - ty * 64 < 64 ? HH - ty * 64 : 64;
+                n += (uint64_t)w * (uint64_t)h;
+            }
+    return n;
 }
 
 int begin_timed(rt_ctx *c) {
@@ -229,17 +260,19 @@ int rt_create(int device, rt_ctx **out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev_begin));
     HIP_TRY(hipEventCreate(&c->ev_end));
-    HIP_TRY(hipMalloc((void **)&c->counters, sizeof(rt::Counters)));
-    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(rt::Counters), c->stream));
-    HIP_TRY(hipMalloc((void **)&c->q.ctl, sizeof(rt::QueueCtl) * (rt::RT_MAX_BOUNCES + 2)));
+    HIP_TRY(hipMalloc((void **)&c->counters, sizeof(rt::Counters) * rt::kCounterStripes));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(rt::Counters) * rt::kCounterStripes, c->stream));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     // persistent traversal kernel: one 64-lane workgroup per wave slot (32 per CU)
     c->extend_waves = (uint32_t)prop.multiProcessorCount * 32u;
     // experiment knobs (defaults are the tuned values)
-    if (const char *e = getenv("RT_PIPELINE")) c->pipeline = (strcmp(e, "mega") == 0) ? 0 : 1;
+    if (const char *e = getenv("RT_PIPELINE")) c->pipeline = (strcmp(e, "wave") == 0) ? 1 : 0;
     if (const char *e = getenv("RT_REFILL")) c->refill_threshold = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_EXTEND_WAVES")) c->extend_waves = (uint32_t)atoi(e);
+    if (const char *e = getenv("RT_LEAF")) c->leaf_threshold = (uint32_t)atoi(e);
+    if (c->leaf_threshold < 1u) c->leaf_threshold = 1u;
+    if (c->leaf_threshold > 64u) c->leaf_threshold = 64u;
     if (c->refill_threshold < 1u) c->refill_threshold = 1u;
     if (c->refill_threshold > 64u) c->refill_threshold = 64u;
     if (c->extend_waves < 1u) c->extend_waves = 1u;
@@ -257,8 +290,7 @@ int rt_destroy(rt_ctx *c) {
         if (b->packed) hipFree(b->packed);
     }
     for (void *p : {(void *)c->sample, (void *)c->acc, (void *)c->sum, (void *)c->aux, (void *)c->counters,
-                    (void *)c->q.rays[0], (void *)c->q.rays[1], (void *)c->q.hits, (void *)c->q.paths,
-                    (void *)c->q.ctl})
+                    (void *)c->q.rays[0], (void *)c->q.hits, (void *)c->q.paths})
         if (p) hipFree(p);
     for (hipEvent_t e : c->ev_trace) hipEventDestroy(e);
     hipEventDestroy(c->ev_begin);
@@ -336,6 +368,7 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounces, 
         p.time = (float)(first_frame + i);  // renderer.py:211 float(self._frames)
         if (int rc = trace_event(c)) return rc;
         trace_frame(c, p, 0, aux, stats);
+        c->pixel_samples += (uint64_t)p.WW * (uint64_t)p.HH;
         if (int rc = trace_event(c)) return rc;
         rt::launch_accumulate(c->sample, c->acc, npix, (float)c->rendered_frames, c->stream);
         c->rendered_frames++;
@@ -388,18 +421,21 @@ int rt_sync(rt_ctx *c) {
 int rt_get_stats(rt_ctx *c, rt_stats *out) {
     if (!c || !out) return fail("rt_get_stats: null argument");
     HIP_TRY(hipSetDevice(c->device));
-    rt::Counters h;
-    HIP_TRY(hipMemcpyAsync(&h, c->counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    rt::Counters hs[rt::kCounterStripes];
+    HIP_TRY(hipMemcpyAsync(hs, c->counters, sizeof hs, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    out->rays = h.rays;
-    out->pixel_samples = h.pixel_samples;
-    out->nodes = h.nodes;
-    out->tri_tests = h.tri_tests;
-    out->sphere_tests = h.sphere_tests;
-    out->box_tests = h.box_tests;
-    out->max_stack = h.max_stack;
-    out->stack_overflows = h.stack_overflows;
-    out->hits = h.hits;
+    memset(out, 0, sizeof *out);
+    for (const rt::Counters &h : hs) {
+        out->rays += h.rays;
+        out->nodes += h.nodes;
+        out->tri_tests += h.tri_tests;
+        out->sphere_tests += h.sphere_tests;
+        out->box_tests += h.box_tests;
+        if (h.max_stack > out->max_stack) out->max_stack = h.max_stack;
+        out->stack_overflows += h.stack_overflows;
+        out->hits += h.hits;
+    }
+    out->pixel_samples = c->pixel_samples;  // known on the host: every launch covers a fixed pixel set
     out->last_render_ms = 0.0;
     out->last_trace_ms = 0.0;
     if (c->timed) {
@@ -419,7 +455,8 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
 int rt_reset_stats(rt_ctx *c) {
     if (!c) return fail("rt_reset_stats: null context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(rt::Counters), c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(rt::Counters) * rt::kCounterStripes, c->stream));
+    c->pixel_samples = 0;
     return 0;
 }
 
@@ -437,11 +474,13 @@ int rt_render_sum(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounc
     p.shard = shard;
     p.nshards = nshards;
     p.bounces = bounces;
+    const uint64_t owned = owned_pixels(p.WW, p.HH, shard, nshards);
     if (int rc = begin_timed(c)) return rc;
     for (uint32_t i = frame_phase; i < nframes; i += frame_stride) {
         p.time = (float)(first_frame + i);
         if (int rc = trace_event(c)) return rc;
         trace_frame(c, p, 1, false, false);
+        c->pixel_samples += owned;
         if (int rc = trace_event(c)) return rc;
     }
     HIP_TRY(hipGetLastError());

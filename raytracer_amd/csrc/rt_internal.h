@@ -34,9 +34,13 @@ struct DevScene {
     uint32_t n_nodes, n_tris, n_spheres, n_boxes, n_planes, n_mats;
     float inv_vp[16];
     float eye[3];
+    float smin[3], sext[3];  // scene_min / scene_extent uniforms (child boxes are decoded with them)
 };
 
-struct Counters {  // lives in device memory, 16 x u64
+// Device-side counters.  To keep same-address atomics rare, the kernels spread their updates over
+// kCounterStripes copies (one 128-byte line each, chosen by workgroup index); the host adds them up.
+constexpr int kCounterStripes = 64;
+struct Counters {  // 16 x u64 = one 128-byte line
     unsigned long long rays, pixel_samples, nodes, tri_tests, sphere_tests, box_tests, max_stack, stack_overflows;
     unsigned long long hits;
     unsigned long long pad[7];
@@ -56,18 +60,11 @@ struct TraceParams {
     uint32_t tiles_x, tiles_y, ntiles;  // 16x16 pixel tiles
 };
 
-// ---- wavefront pipeline: ray queues in device memory ---------------------------------------
-constexpr int RT_MAX_BOUNCES = 66;  // a path never survives bounce index 64 (compute.glsl:430-433)
-struct QueueCtl {
-    uint32_t count;  // rays in this bounce's queue (appended by the previous stage)
-    uint32_t head;   // next unclaimed ray (advanced by the traversal kernel)
-    uint32_t pad[2];
-};
+// ---- wavefront pipeline: ray queue in device memory ----------------------------------------
 struct WaveQueues {
-    float4 *rays[2];  // ping-pong ray records, 2 x float4 per ray
-    float2 *hits;     // per ray of the current queue: distance, primitive metadata word
-    float4 *paths;    // per pixel: 2 x float4 (throughput+rng, light+ior)
-    QueueCtl *ctl;    // RT_MAX_BOUNCES + 2 entries
+    float4 *rays[2];  // [0]: ray records, 2 x float4 per slot ([1] unused)
+    float2 *hits;     // per slot: distance, primitive metadata word
+    float4 *paths;    // per slot: 2 x float4 (throughput+rng, light+ior)
 };
 
 // repack kernels: reference byte layouts -> device records (n elements + 1 zero-source sentinel)
@@ -82,7 +79,7 @@ void launch_copy_raw32(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t
 void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s);
 // one frame through the wavefront pipeline: generate, then per bounce extend + shade
 void launch_wavefront_frame(const TraceParams &p, const WaveQueues &q, int mode, bool aux, bool stats,
-                            uint32_t extend_waves, uint32_t refill_threshold, hipStream_t s);
+                            uint32_t extend_waves, uint32_t refill_threshold, uint32_t leaf_threshold, hipStream_t s);
 // accumulate pass: acc = srgb(lin(acc) + (lin(sample) - lin(acc)) / (frames + 1))
 void launch_accumulate(const float4 *sample, float4 *acc, size_t npixels, float frames, hipStream_t s);
 // acc = srgb(sum / spp)

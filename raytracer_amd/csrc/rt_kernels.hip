@@ -27,6 +27,14 @@ namespace rt {
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 5  // megakernel: waves per SIMD the register allocator must leave room for
 #endif
+// Node records in device memory: 0 = 128-byte pre-decoded fp32 node (7 x 16-byte requests per
+// visit, no decode arithmetic); 1 = the reference's 64-byte quantised node decoded on the fly
+// (4 requests per visit, two nodes per 128-byte line, +170 VALU operations per visit).  Both give
+// identical results; the kernel is limited by VALU issue rather than by cache requests, and the
+// pre-decoded form measured 9 % faster on the 265 k-triangle scene.
+#ifndef RT_NODE64
+#define RT_NODE64 0
+#endif
 #ifndef RT_EXT_STACK_LDS
 #define RT_EXT_STACK_LDS 16  // traversal kernel of the wavefront pipeline: 4 KB of LDS per wavefront
 #endif
@@ -143,6 +151,20 @@ __device__ __forceinline__ float l2s(float c) {
     return (1.0f + 0.055f) * d_pow(c, 1.0f / 2.4f) - 0.055f;
 }
 
+// Child box coordinate from its 16-bit code, compute.glsl:244-261:
+//   f = float(q) / 65535.0 ; coord = scene_min + f * scene_extent
+// The IEEE quotient is produced without a divide: with c = RN(1/65535), q0 = q*c,
+// r = fma(-q0, 65535, q), f = fma(r, c, q0) equals q/65535 correctly rounded for every
+// q in [0, 65535] (checked exhaustively in tests/test_decode_exact.py).
+__device__ __forceinline__ float dequant(uint32_t q, float mn, float ex) {
+    const float c = 1.0f / 65535.0f;
+    float qf = (float)q;
+    float q0 = qf * c;
+    float r = __builtin_fmaf(-q0, 65535.0f, qf);
+    float f = __builtin_fmaf(r, c, q0);
+    return mn + f * ex;
+}
+
 // compute.glsl:749-760
 __device__ __forceinline__ float draw(uint32_t &s) {
     s = (s ^ 61u) ^ (s >> 16);
@@ -158,7 +180,8 @@ __device__ __forceinline__ float draw(uint32_t &s) {
 // Every derived value is computed with exactly the operations the shader would apply per use,
 // so hoisting it here cannot change a result bit.
 // ------------------------------------------------------------------------------------------
-// BVH node, compute.glsl:244-261: f = float(q)/65535.0 ; coord = scene_min + f*scene_extent
+// BVH node.  RT_NODE64: kept in the reference's 64-byte form (plus the all-zero sentinel).
+// Otherwise decoded once here, compute.glsl:244-261: f = float(q)/65535.0 ; coord = scene_min + f*scene_extent
 __global__ void repack_nodes_kernel(const uint32_t *__restrict__ src, uint32_t n, float3 smin, float3 sext,
                                     float4 *__restrict__ dst) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,6 +189,11 @@ __global__ void repack_nodes_kernel(const uint32_t *__restrict__ src, uint32_t n
     uint32_t w[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) w[k] = (i < n) ? src[(size_t)i * 16 + k] : 0u;
+#if RT_NODE64
+    uint4 *o = reinterpret_cast<uint4 *>(dst) + (size_t)i * 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+#else
     const float mn[3] = {smin.x, smin.y, smin.z}, ex[3] = {sext.x, sext.y, sext.z};
     float lo[3][4], hi[3][4];
 #pragma unroll
@@ -185,6 +213,7 @@ __global__ void repack_nodes_kernel(const uint32_t *__restrict__ src, uint32_t n
     }
     o[6] = make_float4(u2f(w[12]), u2f(w[13]), u2f(w[14]), u2f(w[15]));
     o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
 }
 
 // Triangle, compute.glsl:880-881: edge1 = v1 - v0, edge2 = v2 - v0
@@ -355,9 +384,14 @@ __device__ __forceinline__ bool box_distance(v3 O, v3 D, v3 b0, v3 b1, float &t_
 // child boxes, sort, visit far to near (leaves are intersected at once, inner children pushed).
 // `stack` is this lane's column of the LDS stack (element stride STRIDE), `spill` its private
 // overflow array.  best/best_code: distance and metadata word of the best hit so far.
+struct LeafList {
+    uint32_t l0, l1, l2, l3;  // metadata words of the pending leaves, l0 is tested first
+    int n;
+};
+
 template <bool STATS, int STRIDE, int LDS_DEPTH>
-__device__ __forceinline__ void node_step(const DevScene &sc, v3 O, v3 D, v3 ID, float &best, uint32_t &best_code,
-                                          int &sp, uint32_t *stack, uint32_t *spill, LaneStats &st) {
+__device__ __forceinline__ void node_part(const DevScene &sc, v3 O, v3 ID, float best, int &sp, uint32_t *stack,
+                                          uint32_t *spill, LeafList &ll, LaneStats &st) {
     if (STATS) {
         st.max_sp = max(st.max_sp, (uint32_t)sp);
         st.nodes++;
@@ -365,8 +399,25 @@ __device__ __forceinline__ void node_step(const DevScene &sc, v3 O, v3 D, v3 ID,
     --sp;
     uint32_t ni = (sp < LDS_DEPTH) ? stack[sp * STRIDE] : spill[sp - LDS_DEPTH];
     ni = min(ni, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
+#if RT_NODE64
+    const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes) + (size_t)ni * 4;
+    uint4 ax = np[0], ay = np[1], az = np[2], mw = np[3];
+    float4 lox, hix, loy, hiy, loz, hiz;
+#define DQ(c)                                                 \
+    lox.c = dequant(ax.c & 0xFFFFu, sc.smin[0], sc.sext[0]);  \
+    hix.c = dequant(ax.c >> 16, sc.smin[0], sc.sext[0]);      \
+    loy.c = dequant(ay.c & 0xFFFFu, sc.smin[1], sc.sext[1]);  \
+    hiy.c = dequant(ay.c >> 16, sc.smin[1], sc.sext[1]);      \
+    loz.c = dequant(az.c & 0xFFFFu, sc.smin[2], sc.sext[2]);  \
+    hiz.c = dequant(az.c >> 16, sc.smin[2], sc.sext[2]);
+    DQ(x) DQ(y) DQ(z) DQ(w)
+#undef DQ
+    uint32_t m0 = mw.x, m1 = mw.y, m2 = mw.z, m3 = mw.w;
+#else
     const float4 *np = sc.nodes + (size_t)ni * kNodeVec;
     float4 lox = np[0], hix = np[1], loy = np[2], hiy = np[3], loz = np[4], hiz = np[5], mt = np[6];
+    uint32_t m0 = f2u(mt.x), m1 = f2u(mt.y), m2 = f2u(mt.z), m3 = f2u(mt.w);
+#endif
     float k0, k1, k2, k3;
     bool v0, v1, v2, v3_;
     // compute.glsl:186-208, one child per macro expansion
@@ -382,52 +433,92 @@ __device__ __forceinline__ void node_step(const DevScene &sc, v3 O, v3 D, v3 ID,
     }
     SLAB(x, k0, v0) SLAB(y, k1, v1) SLAB(z, k2, v2) SLAB(w, k3, v3_)
 #undef SLAB
-    uint32_t m0 = f2u(mt.x), m1 = f2u(mt.y), m2 = f2u(mt.z), m3 = f2u(mt.w);
     // compute.glsl:210-223
     CSWAP(k0, k1, m0, m1, v0, v1)
     CSWAP(k2, k3, m2, m3, v2, v3_)
     CSWAP(k0, k2, m0, m2, v0, v2)
     CSWAP(k1, k3, m1, m3, v1, v3_)
     CSWAP(k1, k2, m1, m2, v1, v2)
-    // compute.glsl:290-326: far to near
-#define VISIT(VAL, META)                                                                          \
-    if (VAL) {                                                                                    \
-        uint32_t type = META >> 30, idx = META & 0x3FFFFFFFu;                                     \
-        if (type == 3u) {                                                                         \
-            if (sp < LDS_DEPTH) {                                                                 \
-                stack[sp * STRIDE] = idx;                                                         \
-                sp++;                                                                             \
-            } else if (sp < LDS_DEPTH + RT_STACK_SPILL) {                                         \
-                spill[sp - LDS_DEPTH] = idx;                                                      \
-                sp++;                                                                             \
-            } else {                                                                              \
-                st.overflow++;                                                                    \
-            }                                                                                     \
+    // compute.glsl:290-326: children are visited far to near; an inner child is pushed, a leaf is
+    // intersected at once.  Pushing and intersecting do not influence each other, so the visit is
+    // split in two passes that keep each kind in the reference's order: first the pushes
+    // (k = 3..0), then the leaves (k = 3..0) from a per-lane list.  The wavefront then runs the
+    // intersection code once per list position instead of once per child slot.
+    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+    int nl = 0;
+#define PUSH_INNER(VAL, META)                                                                     \
+    if (VAL && (META >> 30) == 3u) {                                                              \
+        uint32_t idx = META & 0x3FFFFFFFu;                                                        \
+        if (sp < LDS_DEPTH) {                                                                     \
+            stack[sp * STRIDE] = idx;                                                             \
+            sp++;                                                                                 \
+        } else if (sp < LDS_DEPTH + RT_STACK_SPILL) {                                             \
+            spill[sp - LDS_DEPTH] = idx;                                                          \
+            sp++;                                                                                 \
         } else {                                                                                  \
-            float t;                                                                              \
-            bool hit;                                                                             \
-            if (type == 0u) {                                                                     \
-                const float4 *tp = sc.tris + (size_t)min(idx, sc.n_tris) * kTriVec;               \
-                if (STATS) st.tri++;                                                              \
-                hit = tri_distance(O, D, tp[0], tp[1], tp[2], t);                                 \
-            } else if (type == 1u) {                                                              \
-                const float4 *spn = sc.spheres + (size_t)min(idx, sc.n_spheres) * kSphereVec;     \
-                if (STATS) st.sph++;                                                              \
-                hit = sphere_distance(O, D, spn[0], t);                                           \
-            } else {                                                                              \
-                const float4 *bp = sc.boxes + (size_t)min(idx, sc.n_boxes) * 2;                   \
-                float4 b0 = bp[0], b1 = bp[1];                                                    \
-                if (STATS) st.box++;                                                              \
-                hit = box_distance(O, D, V(b0.x, b0.y, b0.z), V(b1.x, b1.y, b1.z), t);            \
-            }                                                                                     \
-            if (hit && t > 0.0f && t < best - 1e-6f) {                                            \
-                best = t;                                                                         \
-                best_code = META;                                                                 \
-            }                                                                                     \
+            st.overflow++;                                                                        \
         }                                                                                         \
     }
-    VISIT(v3_, m3) VISIT(v2, m2) VISIT(v1, m1) VISIT(v0, m0)
-#undef VISIT
+    PUSH_INNER(v3_, m3) PUSH_INNER(v2, m2) PUSH_INNER(v1, m1) PUSH_INNER(v0, m0)
+#undef PUSH_INNER
+    // build the list by prepending in the order k = 0..3, so that k = 3 ends up in front
+#define ADD_LEAF(VAL, META)                                                                       \
+    {                                                                                             \
+        bool lf = VAL && (META >> 30) != 3u;                                                      \
+        l3 = lf ? l2 : l3;                                                                        \
+        l2 = lf ? l1 : l2;                                                                        \
+        l1 = lf ? l0 : l1;                                                                        \
+        l0 = lf ? META : l0;                                                                      \
+        nl += lf ? 1 : 0;                                                                         \
+    }
+    ADD_LEAF(v0, m0) ADD_LEAF(v1, m1) ADD_LEAF(v2, m2) ADD_LEAF(v3_, m3)
+#undef ADD_LEAF
+    ll.l0 = l0;
+    ll.l1 = l1;
+    ll.l2 = l2;
+    ll.l3 = l3;
+    ll.n = nl;
+}
+
+// Intersects the first pending leaf of the list (compute.glsl:299-322).
+template <bool STATS>
+__device__ __forceinline__ void leaf_one(const DevScene &sc, v3 O, v3 D, float &best, uint32_t &best_code,
+                                         LeafList &ll, LaneStats &st) {
+    uint32_t meta = ll.l0;
+    ll.l0 = ll.l1;
+    ll.l1 = ll.l2;
+    ll.l2 = ll.l3;
+    ll.n--;
+    uint32_t type = meta >> 30, idx = meta & 0x3FFFFFFFu;
+    float t;
+    bool hit;
+    if (type == 0u) {
+        const float4 *tp = sc.tris + (size_t)min(idx, sc.n_tris) * kTriVec;
+        if (STATS) st.tri++;
+        hit = tri_distance(O, D, tp[0], tp[1], tp[2], t);
+    } else if (type == 1u) {
+        const float4 *spn = sc.spheres + (size_t)min(idx, sc.n_spheres) * kSphereVec;
+        if (STATS) st.sph++;
+        hit = sphere_distance(O, D, spn[0], t);
+    } else {
+        const float4 *bp = sc.boxes + (size_t)min(idx, sc.n_boxes) * 2;
+        float4 b0 = bp[0], b1 = bp[1];
+        if (STATS) st.box++;
+        hit = box_distance(O, D, V(b0.x, b0.y, b0.z), V(b1.x, b1.y, b1.z), t);
+    }
+    if (hit && t > 0.0f && t < best - 1e-6f) {
+        best = t;
+        best_code = meta;
+    }
+}
+
+// One iteration of the reference's `while (stackPtr > 0)` loop.
+template <bool STATS, int STRIDE, int LDS_DEPTH>
+__device__ __forceinline__ void node_step(const DevScene &sc, v3 O, v3 D, v3 ID, float &best, uint32_t &best_code,
+                                          int &sp, uint32_t *stack, uint32_t *spill, LaneStats &st) {
+    LeafList ll;
+    node_part<STATS, STRIDE, LDS_DEPTH>(sc, O, ID, best, sp, stack, spill, ll, st);
+    while (ll.n > 0) leaf_one<STATS>(sc, O, D, best, best_code, ll, st);
 }
 
 // Surface attributes of the accepted primitive, derived from (O, D, t, code) exactly as the
@@ -655,14 +746,13 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
     return v;
 }
 
-// one atomic per wavefront per counter
+// one atomic per wavefront per counter, on the stripe of this workgroup
 template <bool STATS>
-__device__ __forceinline__ void flush_counters(Counters *c, uint32_t lane, uint32_t nrays, uint32_t nsamples,
-                                               const LaneStats &st) {
-    uint32_t r = wave_sum(nrays), ps = wave_sum(nsamples), ov = wave_sum(st.overflow);
+__device__ __forceinline__ void flush_counters(Counters *base, uint32_t lane, uint32_t nrays, const LaneStats &st) {
+    Counters *c = base + (blockIdx.x & (uint32_t)(kCounterStripes - 1));
+    uint32_t r = wave_sum(nrays), ov = wave_sum(st.overflow);
     if (lane == 0) {
         if (r) atomicAdd(&c->rays, (unsigned long long)r);
-        if (ps) atomicAdd(&c->pixel_samples, (unsigned long long)ps);
         if (ov) atomicAdd(&c->stack_overflows, (unsigned long long)ov);
     }
     if (STATS) {
@@ -764,7 +854,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(TracePara
             write_aux_tail(p.aux, pix, ps, nrays);
         }
     }
-    flush_counters<STATS>(p.counters, lane, nrays, live ? 1u : 0u, st);
+    flush_counters<STATS>(p.counters, lane, nrays, st);
 }
 
 void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s) {
@@ -787,228 +877,202 @@ void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStrea
 }
 
 // ------------------------------------------------------------------------------------------
-// pipeline B — wavefront: rays live in queues in HBM; per bounce one persistent EXTEND kernel
+// pipeline B — wavefront: rays live in a queue in HBM; per bounce one persistent EXTEND kernel
 // (traversal only, lanes refilled from the queue as they finish) and one SHADE kernel (the rest
-// of the loop body, emits the next bounce's rays compacted).  Same arithmetic per path as the
-// megakernel, only the scheduling differs.
-//   ray record (32 B):   [0] O.xyz, pixel index   [1] D.xyz, bounce-0 marker (unused)
+// of the loop body, rewrites the ray in place for the next bounce).  Same arithmetic per path as
+// the megakernel, only the scheduling differs.  Every pixel-lane of the tile grid owns one queue
+// slot for the whole frame (slot = tile * 256 + lane-in-tile), so no stage needs an atomic; a
+// slot whose path has ended carries the pixel index 0xFFFFFFFF.
+//   ray record (32 B):   [0] O.xyz, pixel index   [1] D.xyz, unused
 //   hit record ( 8 B):   distance, metadata word of the primitive
-//   path record (32 B, indexed by pixel): [0] throughput.rgb, rng   [1] light.rgb, ior
+//   path record (32 B):  [0] throughput.rgb, rng   [1] light.rgb, ior
 // ------------------------------------------------------------------------------------------
-#define RT_CHUNK 128  // rays a wavefront claims from the queue per atomic
+#define RT_DEAD 0xFFFFFFFFu
 
 template <int MODE, bool AUX>
 __global__ __launch_bounds__(RT_BLOCK) void generate_kernel(TraceParams p, WaveQueues q) {
-    __shared__ uint32_t s_base;
-    __shared__ uint32_t s_wave_off[RT_BLOCK / 64];
     const DevScene &sc = p.scene;
     int x, y;
     bool live = tile_pixel(p, MODE == 1, x, y);
-    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t nb = (uint32_t)p.bounces;
+    // slot of this lane: its tile (after the XCD remap) times 256 plus its position in the tile
+    const uint32_t per = (p.ntiles + 7u) / 8u;
+    const uint32_t tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const size_t slot = (size_t)tile * RT_BLOCK + threadIdx.x;
     Path ps;
-    size_t pix = 0;
+    uint32_t pix = RT_DEAD;
     if (live) {
         primary_ray(sc, p.W, p.H, x, y, p.time, ps);
-        pix = (size_t)y * p.W + x;
+        pix = (uint32_t)y * (uint32_t)p.W + (uint32_t)x;
         if (AUX) {
-            reinterpret_cast<uint4 *>(p.aux + pix * 16)[0] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+            reinterpret_cast<uint4 *>(p.aux + (size_t)pix * 16)[0] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
             write_aux_tail(p.aux, pix, ps, 0u);
         }
-        if (nb == 0u) write_pixel<MODE>(p, pix, ps.light);
-    }
-    bool emit = live && nb > 0u;
-    // block-aggregated append: one atomic per workgroup
-    unsigned long long m = __ballot(emit);
-    uint32_t wcount = (uint32_t)__popcll(m);
-    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    if (lane == 0) s_wave_off[wave] = wcount;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int w = 0; w < RT_BLOCK / 64; w++) {
-            uint32_t c = s_wave_off[w];
-            s_wave_off[w] = tot;
-            tot += c;
+        if (nb == 0u) {
+            write_pixel<MODE>(p, pix, ps.light);
+            pix = RT_DEAD;
         }
-        s_base = tot ? atomicAdd(&q.ctl[0].count, tot) : 0u;
     }
-    __syncthreads();
-    if (emit) {
-        uint32_t slot = s_base + s_wave_off[wave] + rank;
-        q.rays[0][(size_t)slot * 2] = make_float4(ps.O.x, ps.O.y, ps.O.z, u2f((uint32_t)pix));
-        q.rays[0][(size_t)slot * 2 + 1] = make_float4(ps.D.x, ps.D.y, ps.D.z, 0.f);
-        q.paths[pix * 2] = make_float4(ps.thr.x, ps.thr.y, ps.thr.z, u2f(ps.rng));
-        q.paths[pix * 2 + 1] = make_float4(ps.light.x, ps.light.y, ps.light.z, ps.ior);
+    if (pix != RT_DEAD) {
+        q.rays[0][slot * 2] = make_float4(ps.O.x, ps.O.y, ps.O.z, u2f(pix));
+        q.rays[0][slot * 2 + 1] = make_float4(ps.D.x, ps.D.y, ps.D.z, 0.f);
+        q.paths[slot * 2] = make_float4(ps.thr.x, ps.thr.y, ps.thr.z, u2f(ps.rng));
+        q.paths[slot * 2 + 1] = make_float4(ps.light.x, ps.light.y, ps.light.z, ps.ior);
+    } else {
+        q.rays[0][slot * 2] = make_float4(0.f, 0.f, 0.f, u2f(RT_DEAD));
     }
-    LaneStats st = {0, 0, 0, 0, 0, 0, 0};
-    flush_counters<false>(p.counters, lane, 0u, live ? 1u : 0u, st);
 }
 
-// Persistent traversal kernel.  Each wavefront loops: lanes whose stack is empty retire their
-// result and are refilled from the queue in batches (wave-uniform chunk cursor, one atomic per
-// RT_CHUNK rays); every lane with work performs one node step per iteration.  Terminates when
-// the queue is exhausted and every lane is idle.
+// Persistent traversal kernel.  Each wavefront owns the 64-slot chunks c = w, w + W, w + 2W, ...
+// of the queue (W = wavefronts launched): a static interleaved partition, so nothing is claimed
+// through memory.  Lanes whose stack is empty retire their result and are refilled in batches;
+// every lane with work performs one node step per iteration.  Terminates when the wavefront's
+// chunks are used up and every lane is idle.
 template <bool STATS>
-__global__ __launch_bounds__(64, RT_EXTEND_MIN_WAVES) void extend_kernel(DevScene sc, WaveQueues q, uint32_t bounce_index,
-                                                                        uint32_t refill_threshold, Counters *counters,
+__global__ __launch_bounds__(64, RT_EXTEND_MIN_WAVES) void extend_kernel(DevScene sc, WaveQueues q, uint32_t n_slots,
+                                                                        uint32_t refill_threshold,
+                                                                        uint32_t leaf_threshold, Counters *counters,
                                                                         uint32_t *aux) {
     __shared__ uint32_t lds_stack[RT_EXT_STACK_LDS * 64];
     uint32_t spill[RT_STACK_SPILL];
     const uint32_t lane = threadIdx.x;
     uint32_t *stack = lds_stack + lane;
-    const uint32_t qi = bounce_index & 1u;
-    const float4 *__restrict__ rays = q.rays[qi];
+    const float4 *__restrict__ rays = q.rays[0];
     float2 *__restrict__ hits = q.hits;
-    QueueCtl *ctl = q.ctl + bounce_index;
-    const uint32_t n_rays = __hip_atomic_load(&ctl->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nrays_done = 0;
-    // wave-uniform chunk cursor
-    uint32_t cur = 0, end = 0;
-    bool exhausted = false;
+    // wave-uniform cursor over this wavefront's chunks
+    uint32_t chunk = blockIdx.x;
+    uint32_t cur = chunk * 64u, end = min(cur + 64u, n_slots);
+    bool exhausted = cur >= n_slots;
     int ray = -1;
     int sp = 0;
     v3 O = V(0, 0, 0), D = V(0, 0, 0), ID = V(0, 0, 0);
     float best = 1e38f;
     uint32_t code = 0xFFFFFFFFu;
-    uint32_t nodes_this_ray = 0;
+    uint32_t nodes_this_ray = 0, pix_this_ray = 0;
+    LeafList ll = {0, 0, 0, 0, 0};
     for (;;) {
-        bool idle = (sp == 0);
+        bool idle = (sp == 0) && (ll.n == 0);
         unsigned long long idle_mask = __ballot(idle);
         uint32_t n_idle = (uint32_t)__popcll(idle_mask);
         if (n_idle >= refill_threshold || n_idle == 64u) {
             if (idle && ray >= 0) {
                 hits[ray] = make_float2(best, u2f(code));
-                if (STATS && aux) {
-                    uint32_t pix = f2u(rays[(size_t)ray * 2].w);
-                    atomicAdd(aux + (size_t)pix * 16 + 3, nodes_this_ray);
-                }
+                if (STATS && aux) atomicAdd(aux + (size_t)pix_this_ray * 16 + 3, nodes_this_ray);
                 nrays_done++;
                 ray = -1;
             }
             if (!exhausted) {
-                // hand the idle lanes consecutive ray indices from the current chunk(s)
+                // hand the idle lanes consecutive slots from the current chunk(s)
                 uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
                 uint32_t given = 0;  // idle lanes served so far (wave-uniform)
                 while (given < n_idle && !exhausted) {
-                    if (cur >= end) {
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(&ctl->head, (uint32_t)RT_CHUNK);
-                        base = __builtin_amdgcn_readfirstlane(base);
-                        if (base >= n_rays) {
-                            exhausted = true;
-                            break;
-                        }
-                        cur = base;
-                        end = min(base + (uint32_t)RT_CHUNK, n_rays);
-                    }
                     uint32_t take = min(n_idle - given, end - cur);
                     if (idle && rank >= given && rank < given + take) {
-                        ray = (int)(cur + (rank - given));
-                        float4 r0 = rays[(size_t)ray * 2], r1 = rays[(size_t)ray * 2 + 1];
-                        O = V(r0.x, r0.y, r0.z);
-                        D = V(r1.x, r1.y, r1.z);
-                        ID = V(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
-                        best = 1e38f;
-                        code = 0xFFFFFFFFu;
-                        stack[0] = 0u;
-                        sp = 1;
-                        nodes_this_ray = 0;
+                        uint32_t slot = cur + (rank - given);
+                        float4 r0 = rays[(size_t)slot * 2];
+                        if (f2u(r0.w) != RT_DEAD) {
+                            float4 r1 = rays[(size_t)slot * 2 + 1];
+                            ray = (int)slot;
+                            pix_this_ray = f2u(r0.w);
+                            O = V(r0.x, r0.y, r0.z);
+                            D = V(r1.x, r1.y, r1.z);
+                            ID = V(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+                            best = 1e38f;
+                            code = 0xFFFFFFFFu;
+                            stack[0] = 0u;
+                            sp = 1;
+                            nodes_this_ray = 0;
+                        }
                     }
                     cur += take;
                     given += take;
+                    if (cur >= end) {
+                        chunk += gridDim.x;
+                        cur = chunk * 64u;
+                        end = min(cur + 64u, n_slots);
+                        if (chunk >= (n_slots + 63u) / 64u) exhausted = true;
+                    }
                 }
             }
-            if (exhausted && __ballot(sp > 0) == 0ull) break;
+            if (exhausted && __ballot(sp > 0 || ll.n > 0) == 0ull) break;
         }
-        if (sp > 0) {
+        // A lane with pending leaves waits (it must intersect them before its next pop, to keep
+        // the reference's order) while the others go on with node steps; the wavefront switches
+        // to a leaf iteration once enough lanes are waiting, or nobody can do a node step.
+        bool pending = ll.n > 0;
+        bool node_ready = (sp > 0) && !pending;
+        uint32_t n_pending = (uint32_t)__popcll(__ballot(pending));
+        bool any_node = __ballot(node_ready) != 0ull;
+        if (n_pending >= leaf_threshold || (n_pending > 0u && !any_node)) {
+            if (pending) leaf_one<STATS>(sc, O, D, best, code, ll, st);
+        } else if (node_ready) {
             if (STATS) nodes_this_ray++;
-            node_step<STATS, 64, RT_EXT_STACK_LDS>(sc, O, D, ID, best, code, sp, stack, spill, st);
+            node_part<STATS, 64, RT_EXT_STACK_LDS>(sc, O, ID, best, sp, stack, spill, ll, st);
         }
     }
-    flush_counters<STATS>(counters, lane, nrays_done, 0u, st);
+    flush_counters<STATS>(counters, lane, nrays_done, st);
 }
 
-// The rest of the loop body for every ray of bounce `bounce_index`, one lane per ray.
+// The rest of the loop body for every live slot, one lane per slot; the surviving ray replaces
+// the old one in place.
 template <int MODE, bool AUX, bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void shade_kernel(TraceParams p, WaveQueues q, uint32_t bounce_index) {
-    __shared__ uint32_t s_base;
-    __shared__ uint32_t s_wave_off[RT_BLOCK / 64];
+__global__ __launch_bounds__(RT_BLOCK) void shade_kernel(TraceParams p, WaveQueues q, uint32_t n_slots,
+                                                        uint32_t bounce_index) {
     const DevScene &sc = p.scene;
-    const uint32_t qi = bounce_index & 1u;
-    const uint32_t n_rays = __hip_atomic_load(&q.ctl[bounce_index].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (blockIdx.x * RT_BLOCK >= n_rays) return;  // whole workgroup beyond the queue
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nb = (uint32_t)p.bounces;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};
-    bool live = i < n_rays, alive = false;
-    Path ps;
-    size_t pix = 0;
-    if (live) {
-        float4 r0 = q.rays[qi][(size_t)i * 2], r1 = q.rays[qi][(size_t)i * 2 + 1];
-        float2 h = q.hits[i];
-        pix = f2u(r0.w);
-        float4 s0 = q.paths[pix * 2], s1 = q.paths[pix * 2 + 1];
-        ps.O = V(r0.x, r0.y, r0.z);
-        ps.D = V(r1.x, r1.y, r1.z);
-        ps.thr = V(s0.x, s0.y, s0.z);
-        ps.rng = f2u(s0.w);
-        ps.light = V(s1.x, s1.y, s1.z);
-        ps.ior = s1.w;
-        bool exists;
-        float thit;
-        alive = bounce<STATS>(sc, ps, h.x, f2u(h.y), bounce_index, exists, thit, st);
-        if (AUX && bounce_index == 0u) {
-            uint32_t *a = p.aux + pix * 16;
-            a[0] = f2u(h.y);
-            a[1] = f2u(thit);
-            a[2] = exists ? 1u : 0u;
-        }
-        alive = alive && (bounce_index + 1u < nb);
-        if (!alive) {
-            write_pixel<MODE>(p, pix, ps.light);
-            if (AUX) write_aux_tail(p.aux, pix, ps, bounce_index + 1u);
+    if (i < n_slots) {
+        float4 r0 = q.rays[0][i * 2];
+        uint32_t pix = f2u(r0.w);
+        if (pix != RT_DEAD) {
+            float4 r1 = q.rays[0][i * 2 + 1];
+            float2 h = q.hits[i];
+            float4 s0 = q.paths[i * 2], s1 = q.paths[i * 2 + 1];
+            Path ps;
+            ps.O = V(r0.x, r0.y, r0.z);
+            ps.D = V(r1.x, r1.y, r1.z);
+            ps.thr = V(s0.x, s0.y, s0.z);
+            ps.rng = f2u(s0.w);
+            ps.light = V(s1.x, s1.y, s1.z);
+            ps.ior = s1.w;
+            bool exists;
+            float thit;
+            bool alive = bounce<STATS>(sc, ps, h.x, f2u(h.y), bounce_index, exists, thit, st);
+            if (AUX && bounce_index == 0u) {
+                uint32_t *a = p.aux + (size_t)pix * 16;
+                a[0] = f2u(h.y);
+                a[1] = f2u(thit);
+                a[2] = exists ? 1u : 0u;
+            }
+            alive = alive && (bounce_index + 1u < nb);
+            if (alive) {
+                q.rays[0][i * 2] = make_float4(ps.O.x, ps.O.y, ps.O.z, u2f(pix));
+                q.rays[0][i * 2 + 1] = make_float4(ps.D.x, ps.D.y, ps.D.z, 0.f);
+                q.paths[i * 2] = make_float4(ps.thr.x, ps.thr.y, ps.thr.z, u2f(ps.rng));
+                q.paths[i * 2 + 1] = make_float4(ps.light.x, ps.light.y, ps.light.z, ps.ior);
+            } else {
+                write_pixel<MODE>(p, pix, ps.light);
+                if (AUX) write_aux_tail(p.aux, pix, ps, bounce_index + 1u);
+                q.rays[0][i * 2] = make_float4(0.f, 0.f, 0.f, u2f(RT_DEAD));
+            }
         }
     }
-    // block-aggregated append of the surviving rays to the other queue
-    unsigned long long m = __ballot(alive);
-    uint32_t wcount = (uint32_t)__popcll(m);
-    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    if (lane == 0) s_wave_off[wave] = wcount;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int w = 0; w < RT_BLOCK / 64; w++) {
-            uint32_t c = s_wave_off[w];
-            s_wave_off[w] = tot;
-            tot += c;
-        }
-        s_base = tot ? atomicAdd(&q.ctl[bounce_index + 1u].count, tot) : 0u;
-    }
-    __syncthreads();
-    if (alive) {
-        uint32_t slot = s_base + s_wave_off[wave] + rank;
-        float4 *out = q.rays[qi ^ 1u];
-        out[(size_t)slot * 2] = make_float4(ps.O.x, ps.O.y, ps.O.z, u2f((uint32_t)pix));
-        out[(size_t)slot * 2 + 1] = make_float4(ps.D.x, ps.D.y, ps.D.z, 0.f);
-        q.paths[pix * 2] = make_float4(ps.thr.x, ps.thr.y, ps.thr.z, u2f(ps.rng));
-        q.paths[pix * 2 + 1] = make_float4(ps.light.x, ps.light.y, ps.light.z, ps.ior);
-    }
-    if (STATS) flush_counters<true>(p.counters, lane, 0u, 0u, st);
+    if (STATS) flush_counters<true>(p.counters, lane, 0u, st);
 }
 
 void launch_wavefront_frame(const TraceParams &p, const WaveQueues &q, int mode, bool aux, bool stats,
-                            uint32_t extend_waves, uint32_t refill_threshold, hipStream_t s) {
+                            uint32_t extend_waves, uint32_t refill_threshold, uint32_t leaf_threshold, hipStream_t s) {
     uint32_t per = (p.ntiles + 7u) / 8u;
     if (per == 0) return;
     const uint32_t nb_raw = (uint32_t)p.bounces;
     const uint32_t nb = nb_raw > 65u ? 65u : nb_raw;  // a path never survives bounce index 64
-    // queue control words (count of every bounce's queue, claim cursor) start at zero
-    hipMemsetAsync(q.ctl, 0, sizeof(QueueCtl) * (RT_MAX_BOUNCES + 2), s);
     dim3 tgrid(per * 8u), block(RT_BLOCK);
+    const uint32_t n_slots = per * 8u * RT_BLOCK;
 #define G(M, A) hipLaunchKernelGGL((generate_kernel<M, A>), tgrid, block, 0, s, p, q)
     if (mode == 0) {
         if (aux) G(0, true);
@@ -1017,16 +1081,16 @@ void launch_wavefront_frame(const TraceParams &p, const WaveQueues &q, int mode,
         G(1, false);
     }
 #undef G
-    const uint32_t max_rays = (uint32_t)p.WW * (uint32_t)p.HH;
-    dim3 sgrid((max_rays + RT_BLOCK - 1) / RT_BLOCK);
+    const uint32_t n_chunks = n_slots / 64u;
+    const uint32_t ewaves = extend_waves < n_chunks ? extend_waves : n_chunks;
     for (uint32_t b = 0; b < nb; b++) {
         if (stats)
-            hipLaunchKernelGGL((extend_kernel<true>), dim3(extend_waves), dim3(64), 0, s, p.scene, q, b,
-                               refill_threshold, p.counters, aux ? p.aux : nullptr);
+            hipLaunchKernelGGL((extend_kernel<true>), dim3(ewaves), dim3(64), 0, s, p.scene, q, n_slots,
+                               refill_threshold, leaf_threshold, p.counters, aux ? p.aux : nullptr);
         else
-            hipLaunchKernelGGL((extend_kernel<false>), dim3(extend_waves), dim3(64), 0, s, p.scene, q, b,
-                               refill_threshold, p.counters, (uint32_t *)nullptr);
-#define S(M, A, T) hipLaunchKernelGGL((shade_kernel<M, A, T>), sgrid, block, 0, s, p, q, b)
+            hipLaunchKernelGGL((extend_kernel<false>), dim3(ewaves), dim3(64), 0, s, p.scene, q, n_slots,
+                               refill_threshold, leaf_threshold, p.counters, (uint32_t *)nullptr);
+#define S(M, A, T) hipLaunchKernelGGL((shade_kernel<M, A, T>), tgrid, block, 0, s, p, q, n_slots, b)
         if (mode == 0) {
             if (aux && stats) S(0, true, true);
             else if (aux) S(0, true, false);
