@@ -191,6 +191,15 @@ def main():
 
     if rank == 0:
         achieved = rays_per_launch * bytes_per_ray / (kernel_ms * 1e-3) / 1e9
+        # memory-side bytes per launch come from separate rocprofv3 --pmc passes (they cannot be
+        # collected inside this process); the committed summary is used when it is for this workload
+        traffic = None
+        tj = ROOT / "profiles" / "r1" / "traffic.json"
+        key = f"{name} {args.width}x{args.height} {args.bounces}b"
+        if tj.exists():
+            t = json.loads(tj.read_text())
+            if t.get("workload_key") == key:
+                traffic = (t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
         out = {
             "metric": "Mrays/s", "value": total_rays / elapsed_max / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -204,7 +213,8 @@ def main():
                        "bvh_build_s": round(build_s, 3)},
             "ms_per_frame": kernel_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": rays_per_launch * bytes_per_ray,
                          "kernel": "trace_kernel", "kernel_ms": kernel_ms, "bytes_per_ray": bytes_per_ray,
                          "per_ray": {"node_visits": n_node, "triangle_tests": n_tri, "sphere_tests": n_sph,
                                      "hit_fraction": hit_frac, "rays_per_pixel_sample": rays_per_sample}},
