@@ -46,8 +46,9 @@ def sha(a: np.ndarray | bytes) -> str:
     return hashlib.sha256(b).hexdigest()
 
 
-def run_shader(kind, sdir: Path, w, h, bounces, f0, f1, threads, reps=1):
-    """kind: a refscene.shader_variant name, or ("capture", bounce, expr)."""
+def run_shader(kind, sdir: Path, w, h, bounces, f0, f1, threads, reps=1, accumulate=False):
+    """kind: a refscene.shader_variant name, or ("capture", bounce, expr).
+    accumulate: also run the reference's screen shaders after every frame; returns (img, acc, info)."""
     with tempfile.TemporaryDirectory(prefix="rtgold_") as td:
         sp = Path(td) / "variant.glsl"
         if isinstance(kind, tuple):
@@ -58,8 +59,12 @@ def run_shader(kind, sdir: Path, w, h, bounces, f0, f1, threads, reps=1):
         cmd = [str(RUNNER), "--shader", str(sp), "--w", str(w), "--h", str(h), "--bounces", str(bounces),
                "--frames", str(f0), str(f1), "--uniforms", str(sdir / "uniforms.bin"), "--out", str(out),
                "--reps", str(reps)]
+        acc_out = Path(td) / "acc.bin"
+        if accumulate:
+            cmd += ["--screen-vs", str(REF / "shaders" / "screen_vertex.glsl"),
+                    "--screen-fs", str(REF / "shaders" / "screen_fragment.glsl"), "--acc-out", str(acc_out)]
         for flag, name in (("--bvh", "bvh.bin"), ("--tris", "tris.bin"), ("--spheres", "spheres.bin"),
-                           ("--mats", "mats.bin")):
+                           ("--mats", "mats.bin"), ("--boxes", "boxes.bin"), ("--planes", "planes.bin")):
             if (sdir / name).exists() and (sdir / name).stat().st_size:
                 cmd += [flag, str(sdir / name)]
         env = dict(os.environ, LP_NUM_THREADS=str(threads))
@@ -68,6 +73,8 @@ def run_shader(kind, sdir: Path, w, h, bounces, f0, f1, threads, reps=1):
             raise RuntimeError(f"runner failed: {r.stderr}")
         info = json.loads(r.stdout.strip().splitlines()[-1])
         img = np.fromfile(out, dtype=np.float32).reshape(f1 - f0, h, w, 4)
+        if accumulate:
+            return img, np.fromfile(acc_out, dtype=np.float32).reshape(f1 - f0, h, w, 4), info
         return img, info
 
 
@@ -86,7 +93,9 @@ def write_scene(name: str, toml_text: str, meshes, camera: Camera | None = None,
     inv_vp, eye = cam.uniforms_f32()
     uni = np.concatenate([inv_vp, eye, b["scene_min"], b["scene_extent"]]).astype(np.float32)
     meta = {"name": name, "meshes": meshes, "sha256": {}, "nbytes": {}}
-    for key in ("mats", "spheres", "tris", "bvh"):
+    for key in ("mats", "spheres", "tris", "bvh", "boxes", "planes"):
+        if key in ("boxes", "planes") and not b[key]:
+            continue
         meta["sha256"][key] = sha(b[key])
         meta["nbytes"][key] = len(b[key])
         (sdir / f"{key}.bin").write_bytes(b[key])
@@ -136,6 +145,48 @@ def golden_state(sdir: Path, tag, w, h, bounces, frame, threads, capture_bounces
     (sdir / f"{tag}.state.json").write_text(json.dumps(
         {"w": w, "h": h, "bounces": bounces, "frame": frame, "capture_bounces": list(capture_bounces),
          "exprs": STATE_EXPRS}, indent=1))
+
+
+def golden_accumulation(sdir: Path, tag, w, h, bounces, nframes, threads, keep=(0, 1)):
+    """The reference's running mean (screen_fragment.glsl:94-108 driven as renderer.py:249-288 drives
+    it) after each of nframes frames: hashes of all, full images of the frames in `keep` and the last."""
+    img, acc, _ = run_shader("color", sdir, w, h, bounces, 0, nframes, threads, accumulate=True)
+    keep = sorted(set(keep) | {nframes - 1})
+    rec = {"w": w, "h": h, "bounces": bounces, "frames": [0, nframes], "kept": keep,
+           "sample_sha256_per_frame": [sha(img[i]) for i in range(nframes)],
+           "acc_sha256_per_frame": [sha(acc[i]) for i in range(nframes)]}
+    np.savez_compressed(sdir / f"{tag}.acc.npz", **{f"acc{i}": acc[i] for i in keep})
+    (sdir / f"{tag}.acc.json").write_text(json.dumps(rec, indent=1))
+    return rec
+
+
+def prims_toml() -> str:
+    """Boxes and planes: the kernel's other two primitive kinds (compute.glsl:315-323, 788-806), which
+    neither reference scene uses.  Same TOML schema; [[boxes]] as scene.py:125-147 reads them
+    (p0, p1, material), [[planes]] by analogy (point, normal, material)."""
+    out = ['title = "boxes and planes"', ""]
+    mats = ["color = [1.0, 1.0, 1.0]\nemission = [1.0, 1.0, 1.0, 9.0]",
+            "color = [0.8, 0.8, 0.8]",
+            "color = [0.9, 0.3, 0.2]\nsmoothness = 0.4",
+            "color = [0.2, 0.5, 0.9]\nsmoothness = 0.9\nmetallic = 0.7",
+            "color = [0.9, 0.9, 0.9]\nsmoothness = 1.0\ntransmission = 0.9\nior = 1.5",
+            "color = [0.3, 0.8, 0.4]\nsmoothness = 0.2",
+            "color = [0.7, 0.7, 0.2]\nsmoothness = 0.6\nmetallic = 0.3",
+            "color = [1.0, 0.8, 0.6]\nemission = [1.0, 0.8, 0.6, 3.0]"]
+    for m in mats:
+        out.append("[[materials]]\n" + m + "\n")
+    out.append("[[spheres]]\ncenter = [-1.5, 0.6, 0.3]\nradius = 0.6\nmaterial = 4\n")
+    out.append("[[spheres]]\ncenter = [0.5, 0.35, -2.2]\nradius = 0.35\nmaterial = 3\n")
+    boxes = [([-3.5, 0.0, -1.6], [-2.3, 1.4, -0.6], 2), ([-0.4, 0.0, 1.2], [0.9, 0.8, 2.6], 3),
+             ([-2.8, 0.0, 1.9], [-2.0, 2.2, 2.7], 4), ([1.6, 1.0, -0.5], [0.8, 0.0, 0.4], 5),
+             ([-5.0, 0.0, -3.5], [-4.2, 3.0, 3.5], 6), ([-1.0, 2.4, -1.0], [0.2, 2.6, 0.2], 7)]
+    for p0, p1, m in boxes:
+        out.append(f"[[boxes]]\np0 = {p0}\np1 = {p1}\nmaterial = {m}\n")
+    out.append("[[quads]]\ncenter = [-1.0, 5.0, 0.0]\nwidth = 9\nheight = 9\nnormal = [0.0, -1.0, 0.0]\nmaterial = 0\n")
+    out.append("[[quads]]\ncenter = [-2.0, 2.0, -6.0]\nwidth = 12\nheight = 6\nnormal = [0.0, 0.0, 1.0]\nmaterial = 5\n")
+    out.append("[[planes]]\npoint = [0.0, 0.0, 0.0]\nnormal = [0.0, 1.0, 0.0]\nmaterial = 1\n")
+    out.append("[[planes]]\npoint = [-8.0, 0.0, 0.0]\nnormal = [1.0, 0.0, 0.0]\nmaterial = 6\n")
+    return "\n".join(out)
 
 
 def test_toml_with_mesh() -> str:
@@ -242,6 +293,40 @@ def main():
         golden_frames(s, "small_160x88_b6", 160, 88, 6, 0, 2, T, store_full=True, kinds=("color", "primary"))
         golden_frames(s, "mid_640x360_b5", 640, 360, 5, 0, 3, T, store_full=False, kinds=("color", "primary", "counters"))
         golden_state(s, "state_160x88_b4_f1", 160, 88, 4, 1, T)
+    if want("accum"):
+        for name in ("debug", "gally"):
+            golden_accumulation(GOLD / name, "accum_160x88_b4", 160, 88, 4, 12, T)
+    if want("prims"):
+        s = write_scene("prims", prims_toml(), [])
+        golden_frames(s, "small_160x88_b5", 160, 88, 5, 0, 2, T, store_full=True, kinds=("color", "primary", "counters"))
+        golden_frames(s, "mid_640x360_b4", 640, 360, 4, 0, 3, T, store_full=False, kinds=("color", "primary", "counters"))
+        golden_state(s, "state_160x88_b4_f1", 160, 88, 4, 1, T)
+        golden_accumulation(s, "accum_160x88_b4", 160, 88, 4, 6, T)
+    if want("configs"):
+        # the full-size single-GPU configurations: per-frame hashes of every sample image, and of the
+        # running mean after every frame (hash only; nothing of this size is stored whole)
+        s = GOLD / "gally"
+        img, acc, info = run_shader("color", s, 1920, 1080, 4, 0, 64, T, accumulate=True)
+        (s / "c3full_1920x1080_b4.acc.json").write_text(json.dumps(
+            {"w": 1920, "h": 1080, "bounces": 4, "frames": [0, 64], "kept": [],
+             "sample_sha256_per_frame": [sha(img[i]) for i in range(64)],
+             "acc_sha256_per_frame": [sha(acc[i]) for i in range(64)], "llvmpipe_ms": info["ms"], "threads": T},
+            indent=1))
+        del img, acc
+        sph = np.load(GOLD / "meshes" / "sphere.npz")["triangles"]
+        with tempfile.TemporaryDirectory(prefix="rtc2_") as td:
+            b = refscene.build_reference_scene(tomli.loads(test_toml_with_mesh()), [(sph, 26)])
+            for key in ("mats", "spheres", "tris", "bvh"):
+                (Path(td) / f"{key}.bin").write_bytes(b[key])
+            inv_vp, eye = Camera().uniforms_f32()
+            np.concatenate([inv_vp, eye, b["scene_min"], b["scene_extent"]]).astype(np.float32).tofile(
+                Path(td) / "uniforms.bin")
+            img, acc, info = run_shader("color", Path(td), 1920, 1080, 4, 0, 16, T, accumulate=True)
+        (GOLD / "c2_sphere_obj_1920x1080_b4.json").write_text(json.dumps(
+            {"scene": "gally/scene.json + meshes/sphere.npz (material 26)", "w": 1920, "h": 1080, "bounces": 4,
+             "frames": [0, 16], "sample_sha256_per_frame": [sha(img[i]) for i in range(16)],
+             "acc_sha256_per_frame": [sha(acc[i]) for i in range(16)], "llvmpipe_ms": info["ms"], "threads": T},
+            indent=1))
     if want("big"):
         # byte-level pins for the native scene pipeline on large inputs: only hashes are kept
         from raytracer_amd import synth

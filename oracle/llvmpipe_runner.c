@@ -16,9 +16,16 @@
  *   llvmpipe_runner --shader S.glsl --w W --h H --bounces B --frames F0 F1
  *       --uniforms U.bin [--bvh f] [--tris f] [--spheres f] [--mats f]
  *       [--planes f] [--boxes f] --out OUT.bin [--reps R]
+ *       [--screen-vs V.glsl --screen-fs F.glsl --acc-out ACC.bin]
  * U.bin: 25 little-endian f32: inverse_view_projection[16] (memory order, sent
  * untransposed), eye[3], scene_min[3], scene_extent[3].
  * OUT.bin: for each frame f in [F0,F1): W*H*4 f32, row 0 = bottom row (GL).
+ * With --screen-vs/--screen-fs/--acc-out every frame is followed by the
+ * reference's accumulate pass (src/renderer/renderer.py:249-288: the screen
+ * shader drawn over a quad into an RGBA32F framebuffer texture with "frames" =
+ * frames accumulated so far, alpha blending on, then glCopyTexSubImage2D into
+ * the previous-frame texture), and ACC.bin receives the framebuffer texture
+ * after every frame, same layout as OUT.bin.
  * stdout: one JSON line with per-frame milliseconds (glFinish-bounded).
  */
 #define _GNU_SOURCE
@@ -73,6 +80,7 @@ static double now_ms(void) {
 
 int main(int argc, char **argv) {
     const char *shader = NULL, *uni = NULL, *out = NULL;
+    const char *screen_vs = NULL, *screen_fs = NULL, *acc_out = NULL;
     const char *buf_path[16] = {0};
     int W = 640, H = 360, f0 = 0, f1 = 1, reps = 1;
     float bounces = 2.0f;
@@ -85,6 +93,9 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--bounces")) bounces = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "--frames")) { f0 = atoi(argv[++i]); f1 = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--reps")) reps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--screen-vs")) screen_vs = argv[++i];
+        else if (!strcmp(argv[i], "--screen-fs")) screen_fs = argv[++i];
+        else if (!strcmp(argv[i], "--acc-out")) acc_out = argv[++i];
         else if (!strcmp(argv[i], "--spheres")) buf_path[5] = argv[++i];
         else if (!strcmp(argv[i], "--planes")) buf_path[6] = argv[++i];
         else if (!strcmp(argv[i], "--boxes")) buf_path[7] = argv[++i];
@@ -94,6 +105,10 @@ int main(int argc, char **argv) {
         else { fprintf(stderr, "unknown arg %s\n", argv[i]); return 2; }
     }
     if (!shader || !uni || !out) die("need --shader --uniforms --out");
+    int accumulate = screen_vs || screen_fs || acc_out;
+    if (accumulate && !(screen_vs && screen_fs && acc_out))
+        die("--screen-vs, --screen-fs and --acc-out go together");
+    if (accumulate) reps = 1;
 
     /* ---- bring up llvmpipe through the swrast DRI driver ---- */
     const char *drv = getenv("SWRAST_DRI");
@@ -163,43 +178,107 @@ int main(int argc, char **argv) {
     GLF(PFNGLGETTEXIMAGEPROC, glGetTexImage);
     GLF(PFNGLGETERRORPROC, glGetError);
     GLF(PFNGLCLEARTEXIMAGEPROC, glClearTexImage);
+    GLF(PFNGLGENVERTEXARRAYSPROC, glGenVertexArrays);
+    GLF(PFNGLBINDVERTEXARRAYPROC, glBindVertexArray);
+    GLF(PFNGLENABLEVERTEXATTRIBARRAYPROC, glEnableVertexAttribArray);
+    GLF(PFNGLVERTEXATTRIBPOINTERPROC, glVertexAttribPointer);
+    GLF(PFNGLGENFRAMEBUFFERSPROC, glGenFramebuffers);
+    GLF(PFNGLBINDFRAMEBUFFERPROC, glBindFramebuffer);
+    GLF(PFNGLFRAMEBUFFERTEXTURE2DPROC, glFramebufferTexture2D);
+    GLF(PFNGLCHECKFRAMEBUFFERSTATUSPROC, glCheckFramebufferStatus);
+    GLF(PFNGLDRAWARRAYSPROC, glDrawArrays);
+    GLF(PFNGLACTIVETEXTUREPROC, glActiveTexture);
+    GLF(PFNGLTEXPARAMETERIPROC, glTexParameteri);
+    GLF(PFNGLUNIFORM1IPROC, glUniform1i);
+    GLF(PFNGLCOPYTEXSUBIMAGE2DPROC, glCopyTexSubImage2D);
+    GLF(PFNGLVIEWPORTPROC, glViewport);
+    GLF(PFNGLENABLEPROC, glEnable);
+    GLF(PFNGLBLENDFUNCPROC, glBlendFunc);
 
     fprintf(stderr, "GL_RENDERER: %s\nGL_VERSION: %s\n", (const char *)glGetString(GL_RENDERER),
             (const char *)glGetString(GL_VERSION));
 
-    /* ---- program ---- */
-    size_t slen;
-    char *src = read_file(shader, &slen);
-    GLuint sh = glCreateShader(GL_COMPUTE_SHADER);
-    const char *srcs[1] = {src};
-    glShaderSource(sh, 1, srcs, NULL);
-    glCompileShader(sh);
+    /* ---- programs ---- */
+    const char *stage_path[3] = {shader, screen_vs, screen_fs};
+    const GLenum stage_kind[3] = {GL_COMPUTE_SHADER, GL_VERTEX_SHADER, GL_FRAGMENT_SHADER};
+    GLuint stage[3] = {0, 0, 0};
     GLint ok = 0;
-    glGetShaderiv(sh, GL_COMPILE_STATUS, &ok);
-    if (!ok) {
-        char log[8192];
-        glGetShaderInfoLog(sh, sizeof log, NULL, log);
-        fprintf(stderr, "compile failed:\n%s\n", log);
-        return 4;
+    for (int i = 0; i < (accumulate ? 3 : 1); i++) {
+        size_t slen;
+        char *src = read_file(stage_path[i], &slen);
+        stage[i] = glCreateShader(stage_kind[i]);
+        const char *srcs[1] = {src};
+        glShaderSource(stage[i], 1, srcs, NULL);
+        glCompileShader(stage[i]);
+        glGetShaderiv(stage[i], GL_COMPILE_STATUS, &ok);
+        if (!ok) {
+            char log[8192];
+            glGetShaderInfoLog(stage[i], sizeof log, NULL, log);
+            fprintf(stderr, "compile of %s failed:\n%s\n", stage_path[i], log);
+            return 4;
+        }
+        free(src);
     }
-    GLuint prog = glCreateProgram();
-    glAttachShader(prog, sh);
+    GLuint prog = glCreateProgram(), screen_prog = 0;
+    glAttachShader(prog, stage[0]);
     glLinkProgram(prog);
     glGetProgramiv(prog, GL_LINK_STATUS, &ok);
+    if (ok && accumulate) {
+        screen_prog = glCreateProgram();
+        glAttachShader(screen_prog, stage[1]);
+        glAttachShader(screen_prog, stage[2]);
+        glLinkProgram(screen_prog);
+        glGetProgramiv(screen_prog, GL_LINK_STATUS, &ok);
+    }
     if (!ok) {
         char log[8192];
-        glGetProgramInfoLog(prog, sizeof log, NULL, log);
+        glGetProgramInfoLog(screen_prog ? screen_prog : prog, sizeof log, NULL, log);
         fprintf(stderr, "link failed:\n%s\n", log);
         return 4;
     }
     glUseProgram(prog);
 
     /* ---- image + buffers ---- */
-    GLuint tex;
-    glGenTextures(1, &tex);
+    /* three RGBA32F textures as reference renderer.py:95-96,153 and :399-433 makes them:
+       tex[0] = compute output, tex[1] = previous accumulation, tex[2] = framebuffer colour */
+    GLuint tex3[3];
+    glGenTextures(3, tex3);
+    for (int i = 0; i < 3; i++) {
+        glBindTexture(GL_TEXTURE_2D, tex3[i]);
+        glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
+        glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
+        glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+        glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+        glTexStorage2D(GL_TEXTURE_2D, 1, GL_RGBA32F, W, H);
+    }
+    GLuint tex = tex3[0], fbo = 0, vao = 0;
     glBindTexture(GL_TEXTURE_2D, tex);
-    glTexStorage2D(GL_TEXTURE_2D, 1, GL_RGBA32F, W, H);
     glBindImageTexture(0, tex, 0, GL_FALSE, 0, GL_READ_WRITE, GL_RGBA32F);
+    if (accumulate) {
+        /* quad of reference src/utils/opengl_utils.py:8-57: x y z u v per vertex */
+        static const float quad[20] = {-1, 1, 0, 0, 1, -1, -1, 0, 0, 0, 1, 1, 0, 1, 1, 1, -1, 0, 1, 0};
+        GLuint vbo;
+        glGenVertexArrays(1, &vao);
+        glGenBuffers(1, &vbo);
+        glBindBuffer(GL_ARRAY_BUFFER, vbo);
+        glBufferData(GL_ARRAY_BUFFER, sizeof quad, quad, GL_STATIC_DRAW);
+        glBindVertexArray(vao);
+        glEnableVertexAttribArray(0);
+        glVertexAttribPointer(0, 3, GL_FLOAT, GL_FALSE, 5 * sizeof(float), (void *)0);
+        glEnableVertexAttribArray(1);
+        glVertexAttribPointer(1, 2, GL_FLOAT, GL_FALSE, 5 * sizeof(float), (void *)(3 * sizeof(float)));
+        glGenFramebuffers(1, &fbo);
+        glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+        glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, tex3[2], 0);
+        if (glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) die("framebuffer incomplete");
+        glViewport(0, 0, W, H);
+        glEnable(GL_BLEND); /* renderer.py:87-89 */
+        glBlendFunc(GL_SRC_ALPHA, GL_ONE_MINUS_SRC_ALPHA);
+        glActiveTexture(GL_TEXTURE1);
+        glBindTexture(GL_TEXTURE_2D, tex3[1]);
+        glActiveTexture(GL_TEXTURE0);
+        glBindTexture(GL_TEXTURE_2D, tex);
+    }
     for (int b = 0; b < 16; b++) {
         if (!buf_path[b]) continue;
         size_t n;
@@ -224,6 +303,9 @@ int main(int argc, char **argv) {
 
     FILE *fo = fopen(out, "wb");
     if (!fo) die("cannot open --out");
+    FILE *fa = accumulate ? fopen(acc_out, "wb") : NULL;
+    if (accumulate && !fa) die("cannot open --acc-out");
+    int accumulated = 0;
     size_t npx = (size_t)W * H;
     float *img = malloc(npx * 4 * sizeof(float));
     printf("{\"w\": %d, \"h\": %d, \"bounces\": %g, \"ms\": [", W, H, bounces);
@@ -248,12 +330,33 @@ int main(int argc, char **argv) {
             double dt = now_ms() - t0;
             if (dt < best) best = dt;
         }
+        glBindTexture(GL_TEXTURE_2D, tex);
         glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, GL_FLOAT, img);
         if (fwrite(img, sizeof(float) * 4, npx, fo) != npx) die("short write");
+        if (accumulate) {
+            glUseProgram(screen_prog);
+            glUniform1i(glGetUniformLocation(screen_prog, "tex"), 0);
+            glUniform1i(glGetUniformLocation(screen_prog, "old_tex"), 1);
+            glUniform1f(glGetUniformLocation(screen_prog, "frames"), (float)accumulated);
+            glUniform1f(glGetUniformLocation(screen_prog, "denoise"), 0.0f);
+            glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+            glBindVertexArray(vao);
+            glDrawArrays(GL_TRIANGLE_STRIP, 0, 4);
+            accumulated++;
+            glBindTexture(GL_TEXTURE_2D, tex3[1]);
+            glCopyTexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, 0, 0, W, H);
+            glFinish();
+            glBindTexture(GL_TEXTURE_2D, tex3[2]);
+            glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, GL_FLOAT, img);
+            if (fwrite(img, sizeof(float) * 4, npx, fa) != npx) die("short write");
+            glBindTexture(GL_TEXTURE_2D, tex);
+            glUseProgram(prog);
+        }
         printf("%s%.3f", first ? "" : ", ", best);
         first = 0;
     }
     printf("], \"gl_error\": %u}\n", glGetError());
     fclose(fo);
+    if (fa) fclose(fa);
     return 0;
 }

@@ -92,6 +92,7 @@ class OracleScene:
             return p.read_bytes() if p.exists() else b""
 
         return cls(bvh=rd("bvh.bin"), tris=rd("tris.bin"), spheres=rd("spheres.bin"), mats=rd("mats.bin"),
+                   boxes=rd("boxes.bin"), planes=rd("planes.bin"),
                    uniforms=np.fromfile(d / "uniforms.bin", dtype=np.float32))
 
     def render(self, w, h, frame, bounces, want_primary=False, want_counters=False, threads=0):

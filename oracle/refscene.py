@@ -35,10 +35,10 @@ def _import_reference():
         sys.path.insert(0, src)
     from bvh import BVHNode, QBVHNode  # noqa: PLC0415
     from material import Material  # noqa: PLC0415
-    from primitive import Sphere, Triangle  # noqa: PLC0415
+    from primitive import Box, Plane, Sphere, Triangle  # noqa: PLC0415
     from utils.utils import quad_to_triangles  # noqa: PLC0415
 
-    return BVHNode, QBVHNode, Material, Sphere, Triangle, quad_to_triangles
+    return BVHNode, QBVHNode, Material, Sphere, Triangle, quad_to_triangles, Box, Plane
 
 
 def read_obj_triangles(path: str | Path) -> np.ndarray:
@@ -74,9 +74,9 @@ def build_reference_scene(scene: dict, mesh_tris: list[tuple[np.ndarray, int]] |
 
     mesh_tris: list of ((n,3,3) float32 triangles, material index) replacing the
     [[meshes]] entries (whose OBJ parsing is not importable).
-    Returns dict(mats, spheres, tris, bvh: bytes; scene_min, scene_extent: f32[3]).
+    Returns dict(mats, spheres, tris, bvh, boxes, planes: bytes; scene_min, scene_extent: f32[3]).
     """
-    BVHNode, QBVHNode, Material, Sphere, Triangle, quad_to_triangles = _import_reference()
+    BVHNode, QBVHNode, Material, Sphere, Triangle, quad_to_triangles, Box, Plane = _import_reference()
     variables = scene.get("variables") or {}
     sink = io.StringIO()
     ctx = contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext()
@@ -129,6 +129,19 @@ def build_reference_scene(scene: dict, mesh_tris: list[tuple[np.ndarray, int]] |
                 prims.append({"primitive": tr, "index": j + max_index, "primitive_type": "triangle"})
                 tri_data.append(tr.ogl_ssbo_data)
         tris_b = np.vstack(tri_data).tobytes() if tri_data else b""
+        # boxes: what scene.py:125-147 intends (the call at :31 is commented out and the function
+        # appends the growing list instead of the primitive; the primitive itself is used here)
+        box_data = []
+        for index, bx in enumerate(scene.get("boxes") or []):
+            bp = Box(p0=_variable(bx.get("p0"), variables), p1=_variable(bx.get("p1"), variables),
+                     material=_variable(bx.get("material"), variables))
+            box_data.append(bp.ogl_ssbo_data)
+            prims.append({"primitive": bp, "index": index, "primitive_type": "box"})
+        boxes_b = np.concatenate(box_data).tobytes() if box_data else b""
+        # planes: no loader exists in the reference; records come from its Plane class
+        plane_data = [Plane(point=pl.get("point"), normal=pl.get("normal"), material=pl.get("material")).ogl_ssbo_data
+                      for pl in scene.get("planes") or []]
+        planes_b = np.concatenate(plane_data).tobytes() if plane_data else b""
         root = BVHNode.build_tree(prims)
         q = QBVHNode.from_bvh(root)
         q.flatten_qbvh()
@@ -140,6 +153,8 @@ def build_reference_scene(scene: dict, mesh_tris: list[tuple[np.ndarray, int]] |
         "spheres": sph_b,
         "tris": tris_b,
         "bvh": bvh_b,
+        "boxes": boxes_b,
+        "planes": planes_b,
         "scene_min": smin,
         "scene_extent": sext,
     }

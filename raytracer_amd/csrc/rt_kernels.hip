@@ -35,6 +35,9 @@ namespace rt {
 #ifndef RT_NODE64
 #define RT_NODE64 0
 #endif
+#ifndef RT_PREFETCH
+#define RT_PREFETCH 0  // megakernel: fetch the next node before intersecting the pending leaves
+#endif
 #ifndef RT_EXT_STACK_LDS
 #define RT_EXT_STACK_LDS 16  // traversal kernel of the wavefront pipeline: 4 KB of LDS per wavefront
 #endif
@@ -389,9 +392,20 @@ struct LeafList {
     int n;
 };
 
+// Raw words of one node as loaded, before any arithmetic: the loads can be issued early and
+// waited for only where node_test first touches them.
+struct NodeRegs {
+#if RT_NODE64
+    uint4 ax, ay, az, mw;
+#else
+    float4 lox, hix, loy, hiy, loz, hiz, mt;
+#endif
+};
+
+// Pops the next node index and issues its loads.
 template <bool STATS, int STRIDE, int LDS_DEPTH>
-__device__ __forceinline__ void node_part(const DevScene &sc, v3 O, v3 ID, float best, int &sp, uint32_t *stack,
-                                          uint32_t *spill, LeafList &ll, LaneStats &st) {
+__device__ __forceinline__ void node_fetch(const DevScene &sc, int &sp, const uint32_t *stack, const uint32_t *spill,
+                                           NodeRegs &nd, LaneStats &st) {
     if (STATS) {
         st.max_sp = max(st.max_sp, (uint32_t)sp);
         st.nodes++;
@@ -401,7 +415,19 @@ __device__ __forceinline__ void node_part(const DevScene &sc, v3 O, v3 ID, float
     ni = min(ni, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
 #if RT_NODE64
     const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes) + (size_t)ni * 4;
-    uint4 ax = np[0], ay = np[1], az = np[2], mw = np[3];
+    nd.ax = np[0], nd.ay = np[1], nd.az = np[2], nd.mw = np[3];
+#else
+    const float4 *np = sc.nodes + (size_t)ni * kNodeVec;
+    nd.lox = np[0], nd.hix = np[1], nd.loy = np[2], nd.hiy = np[3], nd.loz = np[4], nd.hiz = np[5], nd.mt = np[6];
+#endif
+}
+
+// Slab tests, sort, pushes and leaf list for a fetched node.
+template <bool STATS, int STRIDE, int LDS_DEPTH>
+__device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd, v3 O, v3 ID, float best, int &sp,
+                                          uint32_t *stack, uint32_t *spill, LeafList &ll, LaneStats &st) {
+#if RT_NODE64
+    uint4 ax = nd.ax, ay = nd.ay, az = nd.az, mw = nd.mw;
     float4 lox, hix, loy, hiy, loz, hiz;
 #define DQ(c)                                                 \
     lox.c = dequant(ax.c & 0xFFFFu, sc.smin[0], sc.sext[0]);  \
@@ -414,9 +440,8 @@ __device__ __forceinline__ void node_part(const DevScene &sc, v3 O, v3 ID, float
 #undef DQ
     uint32_t m0 = mw.x, m1 = mw.y, m2 = mw.z, m3 = mw.w;
 #else
-    const float4 *np = sc.nodes + (size_t)ni * kNodeVec;
-    float4 lox = np[0], hix = np[1], loy = np[2], hiy = np[3], loz = np[4], hiz = np[5], mt = np[6];
-    uint32_t m0 = f2u(mt.x), m1 = f2u(mt.y), m2 = f2u(mt.z), m3 = f2u(mt.w);
+    float4 lox = nd.lox, hix = nd.hix, loy = nd.loy, hiy = nd.hiy, loz = nd.loz, hiz = nd.hiz;
+    uint32_t m0 = f2u(nd.mt.x), m1 = f2u(nd.mt.y), m2 = f2u(nd.mt.z), m3 = f2u(nd.mt.w);
 #endif
     float k0, k1, k2, k3;
     bool v0, v1, v2, v3_;
@@ -478,6 +503,14 @@ __device__ __forceinline__ void node_part(const DevScene &sc, v3 O, v3 ID, float
     ll.l2 = l2;
     ll.l3 = l3;
     ll.n = nl;
+}
+
+template <bool STATS, int STRIDE, int LDS_DEPTH>
+__device__ __forceinline__ void node_part(const DevScene &sc, v3 O, v3 ID, float best, int &sp, uint32_t *stack,
+                                          uint32_t *spill, LeafList &ll, LaneStats &st) {
+    NodeRegs nd;
+    node_fetch<STATS, STRIDE, LDS_DEPTH>(sc, sp, stack, spill, nd, st);
+    node_test<STATS, STRIDE, LDS_DEPTH>(sc, nd, O, ID, best, sp, stack, spill, ll, st);
 }
 
 // Intersects the first pending leaf of the list (compute.glsl:299-322).
@@ -835,7 +868,22 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(TracePara
             uint32_t code = 0xFFFFFFFFu;
             int sp = 1;
             stack[0] = 0u;
+#if RT_PREFETCH
+            // the next node's loads are issued before the pending leaves are intersected, so the two
+            // memory latencies of an iteration overlap instead of adding up
+            NodeRegs nd;
+            node_fetch<STATS, RT_BLOCK, RT_STACK_LDS>(sc, sp, stack, spill, nd, st);
+            for (;;) {
+                LeafList ll;
+                node_test<STATS, RT_BLOCK, RT_STACK_LDS>(sc, nd, ps.O, ID, best, sp, stack, spill, ll, st);
+                bool more = sp > 0;
+                if (more) node_fetch<STATS, RT_BLOCK, RT_STACK_LDS>(sc, sp, stack, spill, nd, st);
+                while (ll.n > 0) leaf_one<STATS>(sc, ps.O, ps.D, best, code, ll, st);
+                if (!more) break;
+            }
+#else
             while (sp > 0) node_step<STATS, RT_BLOCK, RT_STACK_LDS>(sc, ps.O, ps.D, ID, best, code, sp, stack, spill, st);
+#endif
             nrays++;
             bool exists;
             float thit;

@@ -35,6 +35,10 @@ TRI_DTYPE = np.dtype({"names": ["v0", "material", "v1", "_p1", "v2", "_p2", "nor
 SPHERE_DTYPE = np.dtype({"names": ["center", "radius", "radius2", "material", "_pad"],
                          "formats": [("<f4", 3), "<f4", "<f4", "<u4", ("<f4", 2)],
                          "offsets": [0, 12, 16, 20, 24], "itemsize": 32})
+BOX_DTYPE = np.dtype({"names": ["p0", "material", "p1", "_pad"], "formats": [("<f4", 3), "<u4", ("<f4", 3), "<f4"],
+                      "offsets": [0, 12, 16, 28], "itemsize": 32})
+PLANE_DTYPE = np.dtype({"names": ["point", "material", "normal", "_pad"],
+                        "formats": [("<f4", 3), "<u4", ("<f4", 3), "<i4"], "offsets": [0, 12, 16, 28], "itemsize": 32})
 MATERIAL_DTYPE = np.dtype({"names": ["color", "emission", "properties"], "formats": ["<u4", "<u4", "<u4"],
                            "offsets": [0, 4, 8], "itemsize": 12})
 
@@ -137,6 +141,28 @@ def pack_triangles(verts: np.ndarray, materials) -> tuple[np.ndarray, np.ndarray
     return out, v.min(axis=1), v.max(axis=1)
 
 
+def pack_boxes(p0, p1, materials) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(records, aabb_min, aabb_max) for n axis-aligned boxes given by two opposite corners
+    (src/primitive/box/box.py:40-47,109-133: corners stored as given, AABB = their min / max)."""
+    p0 = np.asarray(p0, dtype=np.float32).reshape(-1, 3)
+    p1 = np.asarray(p1, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros(p0.shape[0], dtype=BOX_DTYPE)
+    out["p0"], out["p1"] = p0, p1
+    out["material"] = np.asarray(materials, dtype=np.uint32)
+    return out, np.minimum(p0, p1), np.maximum(p0, p1)
+
+
+def pack_planes(points, normals, materials) -> np.ndarray:
+    """Records of n unbounded planes (src/primitive/plane/plane.py:37-47,95-107); planes have no
+    bounding box and are not part of the BVH."""
+    points = np.asarray(points, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros(points.shape[0], dtype=PLANE_DTYPE)
+    out["point"] = points
+    out["normal"] = np.asarray(normals, dtype=np.float32).reshape(-1, 3)
+    out["material"] = np.asarray(materials, dtype=np.uint32)
+    return out
+
+
 def quad_to_triangles(center, width, height, normal):
     """Two triangles of a rectangle (utils.py:164-194); double precision, as lists of floats."""
     center = np.array(center, dtype=float)
@@ -216,9 +242,11 @@ def _variable(value, variables):
 class SceneBuffers:
     """Everything ``load_scene`` hands to the renderer."""
 
-    def __init__(self, materials, spheres, triangles, bvh, scene_min, scene_extent):
+    def __init__(self, materials, spheres, triangles, bvh, scene_min, scene_extent, boxes=None, planes=None):
         self.materials, self.spheres, self.triangles, self.bvh = materials, spheres, triangles, bvh
         self.scene_min, self.scene_extent = scene_min, scene_extent
+        self.boxes = np.zeros(0, dtype=BOX_DTYPE) if boxes is None else boxes
+        self.planes = np.zeros(0, dtype=PLANE_DTYPE) if planes is None else planes
 
     def upload(self, renderer) -> None:
         """The reference's upload order and bindings (scene.py:97,122,193,62,70-71)."""
@@ -226,6 +254,11 @@ class SceneBuffers:
         renderer.update_ssbo(renderer.spheres, self.spheres, 5)
         renderer.update_ssbo(renderer.triangles, self.triangles, 12)
         renderer.update_ssbo(renderer.bvh, self.bvh, 11)
+        # bindings 7 and 6: the kernel reads them (compute.glsl:77-82), the reference loader
+        # never fills them (scene.py:31 is commented out); always sent so that a scene without
+        # boxes or planes clears what an earlier scene left
+        renderer.update_ssbo(renderer.boxes, self.boxes, 7)
+        renderer.update_ssbo(renderer.planes, self.planes, 6)
         renderer.scene_min_coords = self.scene_min
         renderer.scene_extent = self.scene_extent
 
@@ -282,12 +315,24 @@ def build_scene(scene: dict, base_dir=".", mesh_override: dict | None = None,
     triangles, t_mn, t_mx = pack_triangles(verts, tri_m)
     tri_index = np.concatenate([np.arange(n_quad_tris, dtype=np.uint32)] + mesh_index)
 
-    aabb_min = np.concatenate([s_mn.reshape(-1, 3), t_mn.reshape(-1, 3)])
-    aabb_max = np.concatenate([s_mx.reshape(-1, 3), t_mx.reshape(-1, 3)])
-    types = np.concatenate([np.ones(len(sph), np.uint8), np.zeros(len(tri_m), np.uint8)])
-    indices = np.concatenate([np.arange(len(sph), dtype=np.uint32), tri_index])
+    # [[boxes]] (p0, p1, material) and [[planes]] (point, normal, material): tables the reference's
+    # schema reserves (scene.py:31,125-147) and its kernel consumes (compute.glsl:315-323,788-806)
+    bxs = scene.get("boxes") or []
+    boxes, b_mn, b_mx = pack_boxes([_f32(_variable(b.get("p0"), variables), 3) for b in bxs],
+                                   [_f32(_variable(b.get("p1"), variables), 3) for b in bxs],
+                                   [int(_variable(b.get("material"), variables)) for b in bxs])
+    pls = scene.get("planes") or []
+    planes = pack_planes([_f32(_variable(p.get("point"), variables), 3) for p in pls],
+                         [_f32(_variable(p.get("normal"), variables), 3) for p in pls],
+                         [int(_variable(p.get("material"), variables)) for p in pls])
+
+    aabb_min = np.concatenate([s_mn.reshape(-1, 3), t_mn.reshape(-1, 3), b_mn.reshape(-1, 3)])
+    aabb_max = np.concatenate([s_mx.reshape(-1, 3), t_mx.reshape(-1, 3), b_mx.reshape(-1, 3)])
+    types = np.concatenate([np.ones(len(sph), np.uint8), np.zeros(len(tri_m), np.uint8),
+                            np.full(len(bxs), 2, np.uint8)])
+    indices = np.concatenate([np.arange(len(sph), dtype=np.uint32), tri_index, np.arange(len(bxs), dtype=np.uint32)])
     bvh, smin, sext = build_qbvh(aabb_min, aabb_max, types, indices)
-    return SceneBuffers(materials, spheres, triangles, bvh, smin, sext)
+    return SceneBuffers(materials, spheres, triangles, bvh, smin, sext, boxes, planes)
 
 
 def load_scene(filepath: str, renderer=None, mesh_override: dict | None = None) -> SceneBuffers:

@@ -18,7 +18,7 @@ def _cases():
     out = []
     for sdir in sorted(p for p in GOLDEN.iterdir() if p.is_dir()):
         for j in sorted(sdir.glob("*.json")):
-            if j.name in ("meta.json", "scene.json") or j.name.endswith(".state.json"):
+            if j.name in ("meta.json", "scene.json") or j.name.endswith((".state.json", ".acc.json")):
                 continue
             out.append((sdir.name, j.stem))
     return out
@@ -72,6 +72,7 @@ def test_primary_hits_match_reference_shader(renderer, scene, tag):
 
 
 @pytest.mark.parametrize("scene,w,h,frame,bounces", [
+    ("prims", 320, 180, 2, 6),
     ("debug", 640, 360, 1, 2), ("debug_box", 320, 180, 3, 5), ("gally", 640, 360, 2, 4),
     ("gally", 256, 144, 9, 8), ("matlab", 640, 360, 1, 6), ("matlab", 1920, 1080, 0, 4),
 ])
@@ -98,6 +99,15 @@ def test_counters_match_oracle(renderer):
         assert s[k] == cnt[k], k
     assert s["pixel_samples"] == 640 * 360
     assert s["stack_overflows"] == 0
+    # boxes and planes
+    load_golden_scene(renderer, "prims")
+    renderer.reset_stats()
+    render_frame(renderer, 640, 360, 1, 4, stats=True)
+    s = renderer.stats()
+    _, cnt = O.OracleScene.from_dir(GOLDEN / "prims").render(640, 360, 1, 4, want_counters=True)
+    assert cnt["box_tests"] > 0
+    for k in ("rays", "nodes", "tri_tests", "sphere_tests", "box_tests", "max_stack"):
+        assert s[k] == cnt[k], k
 
 
 def test_accumulation_matches_oracle(renderer):
@@ -117,6 +127,43 @@ def test_accumulation_matches_oracle(renderer):
     renderer.reset_accumulation()
     assert renderer.rendered_frames == 0
     assert np.array_equal(renderer.read_accumulation(), renderer.read_sample())
+
+
+@pytest.mark.parametrize("scene,tag", [(p.parent.name, p.name[: -len(".acc.json")])
+                                       for p in sorted(GOLDEN.glob("*/*.acc.json"))])
+def test_accumulation_matches_reference_fragment_shader(renderer, scene, tag):
+    """Running mean against what the reference's screen shaders produced on llvmpipe."""
+    rec = json.loads((GOLDEN / scene / f"{tag}.acc.json").read_text())
+    w, h, b = rec["w"], rec["h"], rec["bounces"]
+    load_golden_scene(renderer, scene)
+    renderer.update_size(w, h)
+    renderer.reset_accumulation()
+    for f in range(*rec["frames"]):
+        render_frame(renderer, w, h, f, b)
+        assert sha(renderer.read_sample()) == rec["sample_sha256_per_frame"][f]
+        assert sha(renderer.read_accumulation()) == rec["acc_sha256_per_frame"][f], f"accumulation after frame {f}"
+    assert renderer.rendered_frames == rec["frames"][1]
+
+
+def test_sphere_obj_configuration_all_frames(renderer):
+    """test.toml + sphere.obj at 1920x1080, 4 bounces, 16 samples per pixel: scene from the host
+    pipeline, every sample image and running mean against the reference shaders' hashes."""
+    from raytracer_amd import scene as S
+    from raytracer_amd.camera import Camera
+
+    rec = json.loads((GOLDEN / "c2_sphere_obj_1920x1080_b4.json").read_text())
+    b = S.build_scene(json.loads((GOLDEN / "gally" / "scene.json").read_text()),
+                      extra_meshes=[(np.load(GOLDEN / "meshes" / "sphere.npz")["triangles"], 26)])
+    b.upload(renderer)
+    inv_vp, eye = Camera().uniforms_f32()
+    renderer.set_uniforms(inv_vp, eye)
+    w, h, bn = rec["w"], rec["h"], rec["bounces"]
+    renderer.update_size(w, h)
+    renderer.reset_accumulation()
+    for f in range(*rec["frames"]):
+        render_frame(renderer, w, h, f, bn)
+        assert sha(renderer.read_sample()) == rec["sample_sha256_per_frame"][f], f"sample {f}"
+        assert sha(renderer.read_accumulation()) == rec["acc_sha256_per_frame"][f], f"running mean after {f}"
 
 
 def test_edge_sizes_and_truncated_dispatch(renderer):

@@ -21,7 +21,7 @@ def _cases(golden):
     out = []
     for sdir in sorted(p for p in golden.iterdir() if p.is_dir()):
         for j in sorted(sdir.glob("*.json")):
-            if j.name in ("meta.json", "scene.json") or j.name.endswith(".state.json"):
+            if j.name in ("meta.json", "scene.json") or j.name.endswith((".state.json", ".acc.json")):
                 continue
             out.append((sdir.name, j.stem))
     return out
@@ -125,3 +125,47 @@ def test_known_answers():
     assert L.rto_pow(1.0, 2.4) == 1.0
     assert abs(L.rto_sin(1.0) - np.sin(1.0)) < 2e-7
     assert abs(L.rto_cos(5.0) - np.cos(5.0)) < 2e-7
+
+
+@pytest.mark.parametrize("scene,tag", [(p.parent.name, p.name[: -len(".acc.json")])
+                                       for p in sorted(GOLDEN.glob("*/*.acc.json"))])
+def test_running_mean_bit_exact(scenes, scene, tag):
+    """The accumulate pass (screen_fragment.glsl:94-108) as the reference's own fragment shader
+    computed it on llvmpipe, frame after frame, driven as renderer.py:249-288 drives it."""
+    rec = json.loads((GOLDEN / scene / f"{tag}.acc.json").read_text())
+    kept = np.load(GOLDEN / scene / f"{tag}.acc.npz") if rec["kept"] else {}
+    w, h, b = rec["w"], rec["h"], rec["bounces"]
+    sc = scenes(scene)
+    acc = np.zeros((h, w, 4), np.float32)
+    f0, f1 = rec["frames"]
+    if w > 1000:
+        f1 = f0 + 3  # keep the CPU suite short; the GPU suite checks every frame
+    for f in range(f0, f1):
+        s = sc.render(w, h, f, b)
+        assert sha(s) == rec["sample_sha256_per_frame"][f]
+        acc = O.accumulate(s, acc, f)
+        assert sha(acc) == rec["acc_sha256_per_frame"][f], f"accumulation after frame {f}"
+        if f in rec["kept"]:
+            assert np.array_equal(acc.view(np.uint32), kept[f"acc{f}"].view(np.uint32))
+
+
+def test_sphere_obj_configuration_first_frames():
+    """test.toml + sphere.obj at 1920x1080, 4 bounces (32 k triangles): scene built by the host
+    pipeline, first two frames and their running mean against the reference shaders' hashes."""
+    from raytracer_amd import scene as S
+    from raytracer_amd.camera import Camera
+
+    rec = json.loads((GOLDEN / "c2_sphere_obj_1920x1080_b4.json").read_text())
+    b = S.build_scene(json.loads((GOLDEN / "gally" / "scene.json").read_text()),
+                      extra_meshes=[(np.load(GOLDEN / "meshes" / "sphere.npz")["triangles"], 26)])
+    inv_vp, eye = Camera().uniforms_f32()
+    sc = O.OracleScene(bvh=b.bvh.tobytes(), tris=b.triangles.tobytes(), spheres=b.spheres.tobytes(),
+                       mats=b.materials.tobytes(),
+                       uniforms=np.concatenate([inv_vp, eye, b.scene_min, b.scene_extent]))
+    w, h, bn = rec["w"], rec["h"], rec["bounces"]
+    acc = np.zeros((h, w, 4), np.float32)
+    for f in range(2):
+        s = sc.render(w, h, f, bn)
+        assert sha(s) == rec["sample_sha256_per_frame"][f]
+        acc = O.accumulate(s, acc, f)
+        assert sha(acc) == rec["acc_sha256_per_frame"][f]

@@ -10,7 +10,8 @@ import pytest
 from raytracer_amd import scene as S, synth
 from util import GOLDEN
 
-MESHES = {"debug": [], "debug_box": [("box", 1)], "gally": [("gally", 26)], "matlab": [("gally", 38), ("box", 23)]}
+MESHES = {"debug": [], "debug_box": [("box", 1)], "gally": [("gally", 26)], "matlab": [("gally", 38), ("box", 23)],
+          "prims": []}
 
 
 def _mesh(name):
@@ -27,6 +28,9 @@ def test_buffers_byte_identical_to_reference_loader(name):
     b = S.build_scene(scene, extra_meshes=[(_mesh(m), mat) for m, mat in MESHES[name]])
     for key, arr in (("mats", b.materials), ("spheres", b.spheres), ("tris", b.triangles), ("bvh", b.bvh)):
         assert arr.tobytes() == (GOLDEN / name / f"{key}.bin").read_bytes(), key
+    for key, arr in (("boxes", b.boxes), ("planes", b.planes)):
+        f = GOLDEN / name / f"{key}.bin"
+        assert arr.tobytes() == (f.read_bytes() if f.exists() else b""), key
     u = np.fromfile(GOLDEN / name / "uniforms.bin", dtype=np.float32)
     assert np.array_equal(u[19:22], b.scene_min) and np.array_equal(u[22:25], b.scene_extent)
 

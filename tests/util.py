@@ -14,9 +14,11 @@ def sha(a) -> str:
 
 def load_golden_scene(renderer, scene: str):
     """Uploads the byte buffers of tests/golden/<scene> in the reference loader's order
-    (materials 9, spheres 5, triangles 12, BVH 11; reference scene.py:97,122,193,62)."""
+    (materials 9, spheres 5, triangles 12, BVH 11; reference scene.py:97,122,193,62), then boxes 7
+    and planes 6 (empty for the scenes that have none)."""
     d = GOLDEN / scene
-    for name, binding in (("mats.bin", 9), ("spheres.bin", 5), ("tris.bin", 12), ("bvh.bin", 11)):
+    for name, binding in (("mats.bin", 9), ("spheres.bin", 5), ("tris.bin", 12), ("bvh.bin", 11),
+                          ("boxes.bin", 7), ("planes.bin", 6)):
         data = np.fromfile(d / name, dtype=np.uint8) if (d / name).exists() else np.zeros(0, np.uint8)
         renderer.update_ssbo(0, data, binding)
     u = np.fromfile(d / "uniforms.bin", dtype=np.float32)
