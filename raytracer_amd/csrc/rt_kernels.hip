@@ -35,6 +35,9 @@ namespace rt {
 #ifndef RT_NODE64
 #define RT_NODE64 0
 #endif
+#ifndef RT_LANE_PROFILE
+#define RT_LANE_PROFILE 0  // diagnostic build: with statistics on, box_tests / hits / stack_overflows
+#endif                     // count wavefront-level executions of a node step / leaf test / bounce
 #ifndef RT_PREFETCH
 #define RT_PREFETCH 0  // megakernel: fetch the next node before intersecting the pending leaves
 #endif
@@ -369,6 +372,11 @@ __device__ __forceinline__ bool box_distance(v3 O, v3 D, v3 b0, v3 b1, float &t_
     return true;
 }
 
+// true in exactly one of the lanes that execute it together
+__device__ __forceinline__ bool first_active_lane() {
+    return (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(1));
+}
+
 #define CSWAP(ka, kb, ma, mb, va, vb)  \
     {                                  \
         bool sw_ = (kb < ka);          \
@@ -378,7 +386,7 @@ __device__ __forceinline__ bool box_distance(v3 O, v3 D, v3 b0, v3 b1, float &t_
         uint32_t tm_ = sw_ ? mb : ma;  \
         mb = sw_ ? ma : mb;            \
         ma = tm_;                      \
-        bool tv_ = sw_ ? vb : va;      \
+        uint32_t tv_ = sw_ ? vb : va;  \
         vb = sw_ ? va : vb;            \
         va = tv_;                      \
     }
@@ -411,7 +419,11 @@ __device__ __forceinline__ void node_fetch(const DevScene &sc, int &sp, const ui
         st.nodes++;
     }
     --sp;
-    uint32_t ni = (sp < LDS_DEPTH) ? stack[sp * STRIDE] : spill[sp - LDS_DEPTH];
+    // the LDS row is read unconditionally (clamped), the private rows only by lanes that are
+    // that deep: one plain LDS read on the common path instead of a generic-address load
+    uint32_t ni = stack[min(sp, LDS_DEPTH - 1) * STRIDE];
+    asm volatile("" : "+v"(ni));  // keeps the two reads from being merged into one generic load
+    if (sp >= LDS_DEPTH) ni = spill[sp - LDS_DEPTH];
     ni = min(ni, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
 #if RT_NODE64
     const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes) + (size_t)ni * 4;
@@ -444,7 +456,7 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
     uint32_t m0 = f2u(nd.mt.x), m1 = f2u(nd.mt.y), m2 = f2u(nd.mt.z), m3 = f2u(nd.mt.w);
 #endif
     float k0, k1, k2, k3;
-    bool v0, v1, v2, v3_;
+    uint32_t v0, v1, v2, v3_;  // 1 = the child is visited
     // compute.glsl:186-208, one child per macro expansion
 #define SLAB(c, KEY, VAL)                                                                        \
     {                                                                                            \
@@ -454,7 +466,7 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
         float tN = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f)); \
         float tF = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));              \
         KEY = tN;                                                                                \
-        VAL = (tN <= tF) && (tN < best);                                                         \
+        VAL = ((tN <= tF) && (tN < best)) ? 1u : 0u;                                             \
     }
     SLAB(x, k0, v0) SLAB(y, k1, v1) SLAB(z, k2, v2) SLAB(w, k3, v3_)
 #undef SLAB
@@ -469,10 +481,24 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
     // split in two passes that keep each kind in the reference's order: first the pushes
     // (k = 3..0), then the leaves (k = 3..0) from a per-lane list.  The wavefront then runs the
     // intersection code once per list position instead of once per child slot.
-    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
-    int nl = 0;
-#define PUSH_INNER(VAL, META)                                                                     \
-    if (VAL && (META >> 30) == 3u) {                                                              \
+    const uint32_t in3 = (m3 >= 0xC0000000u) ? v3_ : 0u, in2 = (m2 >= 0xC0000000u) ? v2 : 0u;
+    const uint32_t in1 = (m1 >= 0xC0000000u) ? v1 : 0u, in0 = (m0 >= 0xC0000000u) ? v0 : 0u;
+    if (sp + 4 <= LDS_DEPTH) {
+        // all four candidate rows are in LDS: every child is stored at the running top and only
+        // an inner, visited child advances it, so a skipped child is overwritten by the next one
+        // or left above the final top; no branch, no predicate
+        uint32_t *w = stack + sp * STRIDE;
+        w[0] = m3 & 0x3FFFFFFFu;
+        w += in3 * STRIDE;
+        w[0] = m2 & 0x3FFFFFFFu;
+        w += in2 * STRIDE;
+        w[0] = m1 & 0x3FFFFFFFu;
+        w += in1 * STRIDE;
+        w[0] = m0 & 0x3FFFFFFFu;
+        sp += (int)(in3 + in2 + in1 + in0);
+    } else {
+#define PUSH_INNER(IN, META)                                                                      \
+    if (IN) {                                                                                     \
         uint32_t idx = META & 0x3FFFFFFFu;                                                        \
         if (sp < LDS_DEPTH) {                                                                     \
             stack[sp * STRIDE] = idx;                                                             \
@@ -484,20 +510,22 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
             st.overflow++;                                                                        \
         }                                                                                         \
     }
-    PUSH_INNER(v3_, m3) PUSH_INNER(v2, m2) PUSH_INNER(v1, m1) PUSH_INNER(v0, m0)
+        PUSH_INNER(in3, m3) PUSH_INNER(in2, m2) PUSH_INNER(in1, m1) PUSH_INNER(in0, m0)
 #undef PUSH_INNER
+    }
     // build the list by prepending in the order k = 0..3, so that k = 3 ends up in front
-#define ADD_LEAF(VAL, META)                                                                       \
+    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+#define ADD_LEAF(VAL, IN, META)                                                                   \
     {                                                                                             \
-        bool lf = VAL && (META >> 30) != 3u;                                                      \
+        bool lf = VAL != IN;                                                                      \
         l3 = lf ? l2 : l3;                                                                        \
         l2 = lf ? l1 : l2;                                                                        \
         l1 = lf ? l0 : l1;                                                                        \
         l0 = lf ? META : l0;                                                                      \
-        nl += lf ? 1 : 0;                                                                         \
     }
-    ADD_LEAF(v0, m0) ADD_LEAF(v1, m1) ADD_LEAF(v2, m2) ADD_LEAF(v3_, m3)
+    ADD_LEAF(v0, in0, m0) ADD_LEAF(v1, in1, m1) ADD_LEAF(v2, in2, m2) ADD_LEAF(v3_, in3, m3)
 #undef ADD_LEAF
+    const int nl = (int)((v0 + v1 + v2 + v3_) - (in0 + in1 + in2 + in3));
     ll.l0 = l0;
     ll.l1 = l1;
     ll.l2 = l2;
@@ -551,7 +579,15 @@ __device__ __forceinline__ void node_step(const DevScene &sc, v3 O, v3 D, v3 ID,
                                           int &sp, uint32_t *stack, uint32_t *spill, LaneStats &st) {
     LeafList ll;
     node_part<STATS, STRIDE, LDS_DEPTH>(sc, O, ID, best, sp, stack, spill, ll, st);
+#if RT_LANE_PROFILE
+    if (STATS && first_active_lane()) st.box++;
+    while (ll.n > 0) {
+        if (STATS && first_active_lane()) st.hits++;
+        leaf_one<STATS>(sc, O, D, best, best_code, ll, st);
+    }
+#else
     while (ll.n > 0) leaf_one<STATS>(sc, O, D, best, best_code, ll, st);
+#endif
 }
 
 // Surface attributes of the accepted primitive, derived from (O, D, t, code) exactly as the
@@ -685,7 +721,7 @@ __device__ __forceinline__ bool bounce(const DevScene &sc, Path &ps, float tb, u
         thit = tp;
     }
     if (!exists) return false;
-    if (STATS) st.hits++;
+    if (STATS && !RT_LANE_PROFILE) st.hits++;
     const float4 *mp = sc.mats + (size_t)min(mat, sc.n_mats) * kMatVec;
     float4 q0 = mp[0], q1 = mp[1], q2 = mp[2], q3 = mp[3];
     float smooth = q0.w, trans = q1.w, f0 = q2.w, ior = q3.x, a2 = q3.y;
@@ -863,6 +899,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(TracePara
         const uint32_t nb = (uint32_t)p.bounces;
         uint32_t aux0 = 0xFFFFFFFFu, aux1 = 0u, aux2 = 0u;
         for (uint32_t i = 0; i < nb; i++) {
+#if RT_LANE_PROFILE
+            if (STATS && first_active_lane()) st.overflow++;
+#endif
             v3 ID = V(1.0f / ps.D.x, 1.0f / ps.D.y, 1.0f / ps.D.z);
             float best = 1e38f;
             uint32_t code = 0xFFFFFFFFu;
