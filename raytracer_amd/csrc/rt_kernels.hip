@@ -25,7 +25,7 @@ namespace rt {
 #define RT_STACK_SPILL 44
 #endif
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 5  // megakernel: waves per SIMD the register allocator must leave room for
+#define RT_MIN_WAVES 8  // megakernel: waves per SIMD the register allocator must leave room for
 #endif
 // Node records in device memory: 0 = 128-byte pre-decoded fp32 node (7 x 16-byte requests per
 // visit, no decode arithmetic); 1 = the reference's 64-byte quantised node decoded on the fly
