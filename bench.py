@@ -91,13 +91,30 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    # RT_BENCH_REHEARSE=1: every rank uses GPU 0 and the collectives run over gloo on host copies.
+    # For rehearsing the N>1 control flow on a one-GPU box; never a measurement.
+    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
     dist = torch = None
     if world > 1:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def collective(fn, t, **kw):
+        """Runs a torch.distributed collective on a device tensor (through host memory when rehearsing)."""
+        if rehearse:
+            h = t.cpu()
+            fn(h, **kw)
+            t.copy_(h)
+        else:
+            fn(t, **kw)
 
     from raytracer_amd.camera import Camera
     from raytracer_amd.renderer import Renderer
@@ -160,7 +177,7 @@ def main():
         # the per-launch device time of the trace kernel is read after the timed region
     r.sync()
     if world > 1:
-        dist.reduce(sum_t, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI, once per run
+        collective(dist.reduce, sum_t, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI, once per run
     fence()
     elapsed = time.perf_counter() - t0
     if rank == 0:
@@ -182,9 +199,9 @@ def main():
     if world > 1:
         t = torch.tensor(my, device=f"cuda:{local_rank}")
         tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        collective(dist.all_reduce, tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        collective(dist.all_reduce, tsum, op=dist.ReduceOp.SUM)
         elapsed_max, total_rays = float(tmax[0]), float(tsum[1])
     else:
         elapsed_max, total_rays = elapsed, float(st["rays"])
@@ -204,7 +221,7 @@ def main():
             "metric": "Mrays/s", "value": total_rays / elapsed_max / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearse else "synthetic; REHEARSAL on one shared GPU over gloo, not a measurement",
             "config": {"workload": f"{name} {args.width}x{args.height} 1spp/frame {args.bounces} bounces, "
                                    f"default reference camera; stands in for sponza_full.obj (not distributed)",
                        "triangles": int(bufs.triangles.shape[0]), "bvh_nodes": int(bufs.bvh.shape[0]),
