@@ -14,6 +14,9 @@
 namespace rt {
 
 #define RT_BLOCK 256
+#ifndef RT_TRACE_BLOCK
+#define RT_TRACE_BLOCK 64  // megakernel workgroup: 64 = one wavefront (an 8x8 quarter of a 16x16 tile)
+#endif
 // Traversal stack: the first RT_STACK_LDS entries of every lane live in LDS (lane-contiguous, so
 // conflict-free); deeper entries spill to per-lane private memory.  The reference's own array
 // has 32 entries and no overflow guard; here pushes beyond RT_STACK_LDS + RT_STACK_SPILL are
@@ -38,6 +41,9 @@ namespace rt {
 #ifndef RT_LANE_PROFILE
 #define RT_LANE_PROFILE 0  // diagnostic build: with statistics on, box_tests / hits / stack_overflows
 #endif                     // count wavefront-level executions of a node step / leaf test / bounce
+#ifndef RT_REGTOP
+#define RT_REGTOP 0  // megakernel: keep the next node to visit in a register when the last visit pushed one (measured: no gain)
+#endif
 #ifndef RT_PREFETCH
 #define RT_PREFETCH 0  // megakernel: fetch the next node before intersecting the pending leaves
 #endif
@@ -410,20 +416,8 @@ struct NodeRegs {
 #endif
 };
 
-// Pops the next node index and issues its loads.
-template <bool STATS, int STRIDE, int LDS_DEPTH>
-__device__ __forceinline__ void node_fetch(const DevScene &sc, int &sp, const uint32_t *stack, const uint32_t *spill,
-                                           NodeRegs &nd, LaneStats &st) {
-    if (STATS) {
-        st.max_sp = max(st.max_sp, (uint32_t)sp);
-        st.nodes++;
-    }
-    --sp;
-    // the LDS row is read unconditionally (clamped), the private rows only by lanes that are
-    // that deep: one plain LDS read on the common path instead of a generic-address load
-    uint32_t ni = stack[min(sp, LDS_DEPTH - 1) * STRIDE];
-    asm volatile("" : "+v"(ni));  // keeps the two reads from being merged into one generic load
-    if (sp >= LDS_DEPTH) ni = spill[sp - LDS_DEPTH];
+// Issues the loads of node ni.
+__device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeRegs &nd) {
     ni = min(ni, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
 #if RT_NODE64
     const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes) + (size_t)ni * 4;
@@ -434,10 +428,37 @@ __device__ __forceinline__ void node_fetch(const DevScene &sc, int &sp, const ui
 #endif
 }
 
-// Slab tests, sort, pushes and leaf list for a fetched node.
+// Pops the node index on top of the stack.
+template <int STRIDE, int LDS_DEPTH>
+__device__ __forceinline__ uint32_t stack_pop(int &sp, const uint32_t *stack, const uint32_t *spill) {
+    --sp;
+    // the LDS row is read unconditionally (clamped), the private rows only by lanes that are
+    // that deep: one plain LDS read on the common path instead of a generic-address load
+    uint32_t ni = stack[min(sp, LDS_DEPTH - 1) * STRIDE];
+    asm volatile("" : "+v"(ni));  // keeps the two reads from being merged into one generic load
+    if (sp >= LDS_DEPTH) ni = spill[sp - LDS_DEPTH];
+    return ni;
+}
+
+// Pops the next node index and issues its loads.
 template <bool STATS, int STRIDE, int LDS_DEPTH>
+__device__ __forceinline__ void node_fetch(const DevScene &sc, int &sp, const uint32_t *stack, const uint32_t *spill,
+                                           NodeRegs &nd, LaneStats &st) {
+    if (STATS) {
+        st.max_sp = max(st.max_sp, (uint32_t)sp);
+        st.nodes++;
+    }
+    node_load(sc, stack_pop<STRIDE, LDS_DEPTH>(sp, stack, spill), nd);
+}
+
+// Slab tests, sort, pushes and leaf list for a fetched node.
+// REGTOP: the nearest visited inner child -- the node the next iteration pops -- is handed back in
+// `next` (have_next = true) instead of going through the stack, whenever the pushes took the
+// branch-free path; the caller then skips the pop.
+template <bool STATS, int STRIDE, int LDS_DEPTH, bool REGTOP = false>
 __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd, v3 O, v3 ID, float best, int &sp,
-                                          uint32_t *stack, uint32_t *spill, LeafList &ll, LaneStats &st) {
+                                          uint32_t *stack, uint32_t *spill, LeafList &ll, LaneStats &st,
+                                          uint32_t *next = nullptr, bool *have_next = nullptr) {
 #if RT_NODE64
     uint4 ax = nd.ax, ay = nd.ay, az = nd.az, mw = nd.mw;
     float4 lox, hix, loy, hiy, loz, hiz;
@@ -494,9 +515,20 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
         w += in2 * STRIDE;
         w[0] = m1 & 0x3FFFFFFFu;
         w += in1 * STRIDE;
-        w[0] = m0 & 0x3FFFFFFFu;
-        sp += (int)(in3 + in2 + in1 + in0);
+        if (REGTOP) {
+            // the last child pushed is the lowest k that is visited and inner; it stays in a
+            // register (its row, if written at all, is above the new top)
+            const uint32_t np_ = in3 + in2 + in1 + in0;
+            const uint32_t nx = in0 ? m0 : (in1 ? m1 : (in2 ? m2 : m3));
+            *next = nx & 0x3FFFFFFFu;
+            *have_next = np_ != 0u;
+            sp += (int)np_ - (np_ != 0u ? 1 : 0);
+        } else {
+            w[0] = m0 & 0x3FFFFFFFu;
+            sp += (int)(in3 + in2 + in1 + in0);
+        }
     } else {
+        if (REGTOP) *have_next = false;
 #define PUSH_INNER(IN, META)                                                                      \
     if (IN) {                                                                                     \
         uint32_t idx = META & 0x3FFFFFFFu;                                                        \
@@ -842,13 +874,18 @@ __device__ __forceinline__ void flush_counters(Counters *base, uint32_t lane, ui
 // workgroup, 8x8 per wavefront.  Workgroups that share an XCD (equal blockIdx % 8 under
 // round-robin placement) get a contiguous run of tiles so that their node working sets overlap
 // in that XCD's L2.  Returns false for surplus workgroups and uncovered / unowned pixels.
+template <int BLOCK = RT_BLOCK>
 __device__ __forceinline__ bool tile_pixel(const TraceParams &p, bool sharded, int &x, int &y) {
+    // BLOCK threads = BLOCK/64 wavefronts of a tile; the workgroups of one tile are consecutive
+    // within their XCD's run
+    constexpr uint32_t WPB = BLOCK / 64, GROUPS = 4 / WPB;  // wavefronts per workgroup, workgroups per tile
     uint32_t b = blockIdx.x;
     uint32_t per = (p.ntiles + 7u) / 8u;
-    uint32_t tile = (b & 7u) * per + (b >> 3);
+    uint32_t j = b >> 3;
+    uint32_t tile = (b & 7u) * per + j / GROUPS;
     if (tile >= p.ntiles) return false;
     uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t lane = threadIdx.x & 63u, wave = (j % GROUPS) * WPB + (threadIdx.x >> 6);
     x = (int)(tx * 16u + (wave & 1u) * 8u + (lane & 7u));
     y = (int)(ty * 16u + (wave >> 1) * 8u + (lane >> 3));
     bool live = (x < p.WW) && (y < p.HH);
@@ -883,12 +920,12 @@ __device__ __forceinline__ void write_aux_tail(uint32_t *aux, size_t pix, const 
 // pipeline A — megakernel: one lane = one pixel-sample, the whole of main() (compute.glsl:451-688)
 // ------------------------------------------------------------------------------------------
 template <int MODE, bool AUX, bool STATS>
-__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(TraceParams p) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+__global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(TraceParams p) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_TRACE_BLOCK];
     uint32_t spill[RT_STACK_SPILL];
     const DevScene &sc = p.scene;
     int x, y;
-    bool live = tile_pixel(p, MODE == 1, x, y);
+    bool live = tile_pixel<RT_TRACE_BLOCK>(p, MODE == 1, x, y);
     uint32_t lane = threadIdx.x & 63u;
     uint32_t *stack = lds_stack + threadIdx.x;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};
@@ -911,17 +948,37 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(TracePara
             // the next node's loads are issued before the pending leaves are intersected, so the two
             // memory latencies of an iteration overlap instead of adding up
             NodeRegs nd;
-            node_fetch<STATS, RT_BLOCK, RT_STACK_LDS>(sc, sp, stack, spill, nd, st);
+            node_fetch<STATS, RT_TRACE_BLOCK, RT_STACK_LDS>(sc, sp, stack, spill, nd, st);
             for (;;) {
                 LeafList ll;
-                node_test<STATS, RT_BLOCK, RT_STACK_LDS>(sc, nd, ps.O, ID, best, sp, stack, spill, ll, st);
+                node_test<STATS, RT_TRACE_BLOCK, RT_STACK_LDS>(sc, nd, ps.O, ID, best, sp, stack, spill, ll, st);
                 bool more = sp > 0;
-                if (more) node_fetch<STATS, RT_BLOCK, RT_STACK_LDS>(sc, sp, stack, spill, nd, st);
+                if (more) node_fetch<STATS, RT_TRACE_BLOCK, RT_STACK_LDS>(sc, sp, stack, spill, nd, st);
                 while (ll.n > 0) leaf_one<STATS>(sc, ps.O, ps.D, best, code, ll, st);
                 if (!more) break;
             }
+#elif RT_REGTOP
+            // the node to visit next lives in a register whenever the previous visit pushed one;
+            // the stack (sp entries) holds the rest.  sp + have = the reference's stackPtr.
+            uint32_t cur = 0u;
+            bool have = true;
+            sp = 0;
+            for (;;) {
+                if (STATS) {
+                    st.max_sp = max(st.max_sp, (uint32_t)sp + (have ? 1u : 0u));
+                    st.nodes++;
+                }
+                if (!have) cur = stack_pop<RT_TRACE_BLOCK, RT_STACK_LDS>(sp, stack, spill);
+                NodeRegs nd;
+                node_load(sc, cur, nd);
+                LeafList ll;
+                node_test<STATS, RT_TRACE_BLOCK, RT_STACK_LDS, true>(sc, nd, ps.O, ID, best, sp, stack, spill, ll, st, &cur,
+                                                               &have);
+                while (ll.n > 0) leaf_one<STATS>(sc, ps.O, ps.D, best, code, ll, st);
+                if (!have && sp == 0) break;
+            }
 #else
-            while (sp > 0) node_step<STATS, RT_BLOCK, RT_STACK_LDS>(sc, ps.O, ps.D, ID, best, code, sp, stack, spill, st);
+            while (sp > 0) node_step<STATS, RT_TRACE_BLOCK, RT_STACK_LDS>(sc, ps.O, ps.D, ID, best, code, sp, stack, spill, st);
 #endif
             nrays++;
             bool exists;
@@ -949,7 +1006,7 @@ void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStrea
     // [0, 8*ceil(ntiles/8)) with the surplus workgroups exiting at once
     uint32_t per = (p.ntiles + 7u) / 8u;
     if (per == 0) return;  // image smaller than one dispatch group: the reference dispatches nothing
-    dim3 grid(per * 8u), block(RT_BLOCK);
+    dim3 grid(per * 8u * (RT_BLOCK / RT_TRACE_BLOCK)), block(RT_TRACE_BLOCK);
 #define L(M, A, S) hipLaunchKernelGGL((trace_kernel<M, A, S>), grid, block, 0, s, p)
     if (mode == 0) {
         if (aux && stats) L(0, true, true);

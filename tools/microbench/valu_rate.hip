@@ -1,0 +1,76 @@
+// Issue rate of plain and packed fp32 VALU instructions on one SIMD as a function of the number of
+// resident wavefronts.  Each wavefront runs a long stream of independent multiplies.
+//   hipcc --offload-arch=gfx950 -O3 tools/microbench/valu_rate.hip -o build/valu_rate && build/valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+template <int PACKED>
+__global__ __launch_bounds__(64) void stream_kernel(float *out, int iters, long long *cycles) {
+    float a0 = threadIdx.x * 0.001f + 1.0f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,
+          a6 = a0 + 6, a7 = a0 + 7;
+    float m = 1.0000001f;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, mm = {m, m};
+    long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; i++) {
+        if (PACKED) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(mm));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                             "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+            }
+        }
+    }
+    long long t1 = __builtin_readcyclecounter();
+    float r = PACKED ? (p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y) : (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
+    out[blockIdx.x * 64 + threadIdx.x] = r;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+int main() {
+    int dev = 0;
+    CHECK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, dev));
+    const int cus = prop.multiProcessorCount;
+    float *out;
+    long long *cyc;
+    const int max_blocks = cus * 4 * 8;
+    CHECK(hipMalloc(&out, sizeof(float) * 64 * max_blocks));
+    CHECK(hipMalloc(&cyc, sizeof(long long) * max_blocks));
+    const int iters = 20000;  // 32 instructions per iteration in both variants
+    printf("CUs %d, clock %d kHz\n", cus, prop.clockRate);
+    for (int packed = 0; packed < 2; packed++) {
+        for (int wps = 1; wps <= 8; wps *= 2) {
+            int blocks = cus * 4 * wps;  // one-wave blocks; the dispatcher spreads them over the SIMDs
+            hipEvent_t e0, e1;
+            CHECK(hipEventCreate(&e0));
+            CHECK(hipEventCreate(&e1));
+            for (int rep = 0; rep < 2; rep++) {
+                CHECK(hipEventRecord(e0));
+                if (packed) hipLaunchKernelGGL(stream_kernel<1>, dim3(blocks), dim3(64), 0, 0, out, iters, cyc);
+                else hipLaunchKernelGGL(stream_kernel<0>, dim3(blocks), dim3(64), 0, 0, out, iters, cyc);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+            }
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            double insts_per_simd = (double)iters * 32 * wps;
+            double cycles = ms * 1e-3 * prop.clockRate * 1e3;
+            printf("%s waves/SIMD %d: %.3f ms, %.2f cycles per wave-instruction per SIMD (%s flop-lanes/clk/SIMD %.1f)\n",
+                   packed ? "v_pk_mul_f32" : "v_mul_f32   ", wps, ms, cycles / insts_per_simd, packed ? "128" : "64",
+                   (packed ? 128.0 : 64.0) / (cycles / insts_per_simd));
+        }
+    }
+    return 0;
+}

@@ -4,7 +4,7 @@ import csv, sys, glob, collections
 root = sys.argv[1]
 kern = sys.argv[2] if len(sys.argv) > 2 else "trace_kernel<1"
 acc = collections.defaultdict(list)
-for fn in glob.glob(root + "/*/*/*counter_collection.csv"):
+for fn in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     with open(fn) as f:
         for row in csv.DictReader(f):
             if kern in row["Kernel_Name"]:
