@@ -14,9 +14,7 @@
 namespace rt {
 
 #define RT_BLOCK 256
-#ifndef RT_TRACE_BLOCK
-#define RT_TRACE_BLOCK 64  // megakernel workgroup: 64 = one wavefront (an 8x8 quarter of a 16x16 tile)
-#endif
+#define RT_TRACE_BLOCK 64  // megakernel workgroup: one wavefront (an 8x8 quarter of a 16x16 tile)
 // Traversal stack: the first RT_STACK_LDS entries of every lane live in LDS (lane-contiguous, so
 // conflict-free); deeper entries spill to per-lane private memory.  The reference's own array
 // has 32 entries and no overflow guard; here pushes beyond RT_STACK_LDS + RT_STACK_SPILL are
@@ -41,6 +39,12 @@ namespace rt {
 #ifndef RT_LANE_PROFILE
 #define RT_LANE_PROFILE 0  // diagnostic build: with statistics on, box_tests / hits / stack_overflows
 #endif                     // count wavefront-level executions of a node step / leaf test / bounce
+#ifndef RT_XCD_MAP
+#define RT_XCD_MAP 2  // megakernel tile placement: 0 round-robin tiles, 1 one band of tiles per XCD, 2 macro tiles dealt to XCDs
+#endif
+#ifndef RT_MACRO
+#define RT_MACRO 2    // RT_XCD_MAP 2: macro tile = RT_MACRO x RT_MACRO tiles of 16x16 pixels
+#endif
 #ifndef RT_REGTOP
 #define RT_REGTOP 0  // megakernel: keep the next node to visit in a register when the last visit pushed one (measured: no gain)
 #endif
@@ -897,6 +901,47 @@ __device__ __forceinline__ bool tile_pixel(const TraceParams &p, bool sharded, i
     return live;
 }
 
+// Pixel of a megakernel lane (one-wavefront workgroups, 8x8 pixels each, four per 16x16 tile).
+// Consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2, so b & 7 names
+// the XCD and b >> 3 counts within it.  Macro tiles (RT_MACRO x RT_MACRO tiles) are dealt to the
+// XCDs in turn: an XCD works on compact screen regions (its rays share nodes in its L2) while
+// every XCD gets an equal share of cheap and expensive parts of the image.
+__device__ __forceinline__ bool trace_pixel(const TraceParams &p, bool sharded, int &x, int &y) {
+    const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u;
+    uint32_t tx, ty, wave;
+#if RT_XCD_MAP == 2
+    const uint32_t mxn = (p.tiles_x + RT_MACRO - 1) / RT_MACRO, myn = (p.tiles_y + RT_MACRO - 1) / RT_MACRO;
+    const uint32_t j = b >> 3, per_macro = RT_MACRO * RT_MACRO * 4u;
+    const uint32_t macro = (j / per_macro) * 8u + (b & 7u), r = j % per_macro;
+    if (macro >= mxn * myn) return false;
+    const uint32_t t = r >> 2;
+    wave = r & 3u;
+    tx = (macro % mxn) * RT_MACRO + (t % RT_MACRO);
+    ty = (macro / mxn) * RT_MACRO + (t / RT_MACRO);
+    if (tx >= p.tiles_x || ty >= p.tiles_y) return false;
+#elif RT_XCD_MAP == 1
+    const uint32_t per = (p.ntiles + 7u) / 8u, j = b >> 3;
+    const uint32_t tile = (b & 7u) * per + (j >> 2);
+    if (tile >= p.ntiles) return false;
+    wave = j & 3u;
+    tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+#else
+    const uint32_t tile = b >> 2;
+    if (tile >= p.ntiles) return false;
+    wave = b & 3u;
+    tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+#endif
+    x = (int)(tx * 16u + (wave & 1u) * 8u + (lane & 7u));
+    y = (int)(ty * 16u + (wave >> 1) * 8u + (lane >> 3));
+    bool live = (x < p.WW) && (y < p.HH);
+    if (sharded && p.nshards > 1u) {
+        // 64x64 pixel macro tiles dealt round-robin in Morton order
+        uint32_t owner = morton2((uint32_t)x >> 6, (uint32_t)y >> 6) % p.nshards;
+        live = live && (owner == p.shard);
+    }
+    return live;
+}
+
 // writes a finished pixel-sample: MODE 0 the sRGB-encoded sample image (compute.glsl:673),
 // MODE 1 adds the linear radiance into the sum image
 template <int MODE>
@@ -925,7 +970,7 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
     uint32_t spill[RT_STACK_SPILL];
     const DevScene &sc = p.scene;
     int x, y;
-    bool live = tile_pixel<RT_TRACE_BLOCK>(p, MODE == 1, x, y);
+    bool live = trace_pixel(p, MODE == 1, x, y);
     uint32_t lane = threadIdx.x & 63u;
     uint32_t *stack = lds_stack + threadIdx.x;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};
@@ -1002,11 +1047,17 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
 }
 
 void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s) {
-    // grid: tiles rounded up to a multiple of 8 so the XCD-contiguous remap is a bijection onto
-    // [0, 8*ceil(ntiles/8)) with the surplus workgroups exiting at once
-    uint32_t per = (p.ntiles + 7u) / 8u;
-    if (per == 0) return;  // image smaller than one dispatch group: the reference dispatches nothing
-    dim3 grid(per * 8u * (RT_BLOCK / RT_TRACE_BLOCK)), block(RT_TRACE_BLOCK);
+    if (p.ntiles == 0) return;  // image smaller than one dispatch group: the reference dispatches nothing
+    // 8 equal runs of workgroups, one per XCD; surplus workgroups exit at once
+#if RT_XCD_MAP == 2
+    const uint32_t mx = (p.tiles_x + RT_MACRO - 1) / RT_MACRO, my = (p.tiles_y + RT_MACRO - 1) / RT_MACRO;
+    const uint32_t groups = ((mx * my + 7u) / 8u) * 8u * (RT_MACRO * RT_MACRO * 4u);
+#elif RT_XCD_MAP == 1
+    const uint32_t groups = ((p.ntiles + 7u) / 8u) * 8u * 4u;
+#else
+    const uint32_t groups = p.ntiles * 4u;
+#endif
+    dim3 grid(groups), block(RT_TRACE_BLOCK);
 #define L(M, A, S) hipLaunchKernelGGL((trace_kernel<M, A, S>), grid, block, 0, s, p)
     if (mode == 0) {
         if (aux && stats) L(0, true, true);
