@@ -84,7 +84,10 @@ int rt_set_camera(rt_ctx *ctx, const float inv_view_proj[16], const float eye[3]
  * with time = first_frame + i and the given `bounces` uniform (renderer.py:211-246), then the
  * accumulate pass (shaders/screen_fragment.glsl:94-108, renderer.py:249-288) which folds the
  * sample into the running mean and increments the accumulated-frame count.  Asynchronous;
- * rt_sync or any rt_read_* waits for it. */
+ * rt_sync or any rt_read_* waits for it.  Consecutive frames overlap on the device (the compute
+ * dispatch of frame k+1 may start while frame k drains; the accumulate passes run in frame order),
+ * which changes no result; RT_OVERLAP=0 in the environment at rt_create keeps frames strictly
+ * one after another, and frames with RT_FLAG_AUX always are. */
 int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t nframes, float bounces, uint32_t flags);
 
 /* Renderer.reset_accumulation (renderer.py:326-345): the accumulation image becomes a copy of the
@@ -118,6 +121,13 @@ int rt_sync(rt_ctx *ctx);
  * only frames f with (f - first_frame) % frame_stride == frame_phase are rendered.
  * After the per-GPU buffers are summed (RCCL reduce), rt_finalize_sum turns the sum into the
  * sRGB-encoded mean image.
+ * Two launches are kept in flight: launches alternate, starting after every rt_clear_sum, between
+ * adding into `sum_rgba` and adding into a second image inside the context, which is added to
+ * `sum_rgba` and zeroed by the next rt_sync, rt_finalize_sum, rt_clear_sum, rt_render, rt_get_stats
+ * or a call that names another `sum_rgba`.  `sum_rgba` is therefore complete only after one of those calls
+ * (call rt_sync before handing the buffer to a collective), and holds the fp32 sum
+ * (even launches, in order) + (odd launches, in order): deterministic, though not the same
+ * rounding as one running sum.  RT_OVERLAP=0 gives the single running sum.
  */
 int rt_render_sum(rt_ctx *ctx, uint32_t first_frame, uint32_t nframes, float bounces, uint32_t shard,
                   uint32_t nshards, uint32_t frame_stride, uint32_t frame_phase, float *sum_rgba);

@@ -48,6 +48,24 @@ struct rt_ctx {
     float eye[3] = {0, 0, 0};
     float4 *sample = nullptr, *acc = nullptr, *sum = nullptr;
     uint32_t *aux = nullptr;
+    // Two frames in flight: trace kernels alternate between two streams (and two sample / sum
+    // images), so the ramp-down of one frame overlaps the start of the next; everything else --
+    // uploads, repacks, the accumulate pass, folds, read-backs -- stays on `stream`, ordered
+    // against the trace streams with events.
+    hipStream_t tstream[2] = {nullptr, nullptr};
+    hipEvent_t ev_ready = nullptr;                // `stream` work the trace streams must observe
+    hipEvent_t ev_tdone[2] = {nullptr, nullptr};  // last trace kernel of a trace stream
+    hipEvent_t ev_acc[2] = {nullptr, nullptr};    // last accumulate pass that read sample image b
+    bool main_dirty = true;                       // something was queued on `stream` since ev_ready
+    bool need_ready[2] = {false, false};
+    bool acc_recorded[2] = {false, false};
+    bool tpending[2] = {false, false};            // trace stream has work `stream` does not depend on yet
+    float4 *sample2 = nullptr, *sum2 = nullptr;   // images of the odd frames
+    float4 *sum2_target = nullptr;                // where sum2 is folded into
+    bool sum2_dirty = false;
+    int flip = 0;                                 // parity of the next frame
+    int last_sample = 0;                          // which sample image holds the newest frame
+    bool overlap = true;                          // RT_OVERLAP=0 keeps every kernel on `stream`
     rt::Counters *counters = nullptr;
     uint32_t rendered_frames = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -101,7 +119,7 @@ int vecs_per_elem(int binding) {
 
 int alloc_images(rt_ctx *c) {
     size_t n = (size_t)c->W * c->H;
-    for (float4 **p : {&c->sample, &c->acc, &c->sum}) {
+    for (float4 **p : {&c->sample, &c->sample2, &c->acc, &c->sum, &c->sum2}) {
         if (*p) HIP_TRY(hipFree(*p));
         *p = nullptr;
         HIP_TRY(hipMalloc((void **)p, n * sizeof(float4)));
@@ -122,21 +140,73 @@ int alloc_images(rt_ctx *c) {
     HIP_TRY(hipMalloc((void **)&c->q.hits, slots * sizeof(float2)));
     HIP_TRY(hipMalloc((void **)&c->q.paths, slots * 2 * sizeof(float4)));
     c->rendered_frames = 0;
+    c->main_dirty = true;
+    c->sum2_dirty = false;
+    c->acc_recorded[0] = c->acc_recorded[1] = false;
+    c->flip = c->last_sample = 0;
     return 0;
 }
 
-// one frame on the context's stream with the selected pipeline
-void trace_frame(rt_ctx *c, const rt::TraceParams &p, int mode, bool aux, bool stats) {
+// one frame on stream `s` with the selected pipeline
+void trace_frame(rt_ctx *c, const rt::TraceParams &p, int mode, bool aux, bool stats, hipStream_t s) {
     if (c->pipeline == 0)
-        rt::launch_trace(p, mode, aux, stats, c->stream);
+        rt::launch_trace(p, mode, aux, stats, s);
     else
-        rt::launch_wavefront_frame(p, c->q, mode, aux, stats, c->extend_waves, c->refill_threshold, c->leaf_threshold, c->stream);
+        rt::launch_wavefront_frame(p, c->q, mode, aux, stats, c->extend_waves, c->refill_threshold, c->leaf_threshold, s);
+}
+
+// Makes `stream` depend on everything queued on the trace streams and folds the odd frames' sum
+// image into its target.  After this, work queued on `stream` sees every frame rendered so far.
+int join(rt_ctx *c) {
+    for (int b = 0; b < 2; b++) {
+        if (!c->tpending[b]) continue;
+        HIP_TRY(hipEventRecord(c->ev_tdone[b], c->tstream[b]));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tdone[b], 0));
+        c->tpending[b] = false;
+    }
+    if (c->sum2_dirty) {
+        rt::launch_fold_sum(c->sum2_target, c->sum2, (size_t)c->W * c->H, c->stream);
+        HIP_TRY(hipGetLastError());
+        c->sum2_dirty = false;
+        c->main_dirty = true;
+    }
+    return 0;
+}
+
+// join, then wait on the host
+int sync_all(rt_ctx *c) {
+    if (int rc = join(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Stream for the next frame of parity b.  An overlapped frame goes to trace stream b, which first
+// waits for whatever `stream` has queued that the frame must observe.
+int trace_stream(rt_ctx *c, int b, bool serial, hipStream_t *out) {
+    if (serial) {
+        if (int rc = join(c)) return rc;
+        *out = c->stream;
+        return 0;
+    }
+    if (c->main_dirty) {
+        HIP_TRY(hipEventRecord(c->ev_ready, c->stream));
+        c->main_dirty = false;
+        c->need_ready[0] = c->need_ready[1] = true;
+    }
+    if (c->need_ready[b]) {
+        HIP_TRY(hipStreamWaitEvent(c->tstream[b], c->ev_ready, 0));
+        c->need_ready[b] = false;
+    }
+    *out = c->tstream[b];
+    return 0;
 }
 
 // brings the device records of one binding up to date
 int repack(rt_ctx *c, int binding) {
     RawBuffer *b = buffer_of(c, binding);
     if (!b->dirty) return 0;
+    if (int rc = sync_all(c)) return rc;  // frames in flight still read the old records
+    c->main_dirty = true;
     size_t need = ((size_t)b->count + 1) * vecs_per_elem(binding);
     if (need > b->packed_cap) {
         if (b->packed) HIP_TRY(hipFree(b->packed));
@@ -226,14 +296,14 @@ int begin_timed(rt_ctx *c) {
     return 0;
 }
 
-int trace_event(rt_ctx *c) {  // records the next event of the pool on the stream
+int trace_event(rt_ctx *c, hipStream_t s) {  // records the next event of the pool on stream s
     if (c->ev_trace_used >= c->ev_trace.size()) {
         if (c->ev_trace.size() >= 512) return 0;  // long runs: only the first 256 frames are split out
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         c->ev_trace.push_back(e);
     }
-    HIP_TRY(hipEventRecord(c->ev_trace[c->ev_trace_used++], c->stream));
+    HIP_TRY(hipEventRecord(c->ev_trace[c->ev_trace_used++], s));
     return 0;
 }
 
@@ -260,6 +330,13 @@ int rt_create(int device, rt_ctx **out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev_begin));
     HIP_TRY(hipEventCreate(&c->ev_end));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->tstream[b], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_tdone[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_acc[b], hipEventDisableTiming));
+    }
+    if (const char *e = getenv("RT_OVERLAP")) c->overlap = atoi(e) != 0;
     HIP_TRY(hipMalloc((void **)&c->counters, sizeof(rt::Counters) * rt::kCounterStripes));
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(rt::Counters) * rt::kCounterStripes, c->stream));
     hipDeviceProp_t prop;
@@ -284,17 +361,25 @@ int rt_create(int device, rt_ctx **out) {
 int rt_destroy(rt_ctx *c) {
     if (!c) return 0;
     hipSetDevice(c->device);
+    for (int b = 0; b < 2; b++) hipStreamSynchronize(c->tstream[b]);
     hipStreamSynchronize(c->stream);
     for (RawBuffer *b : {&c->spheres, &c->planes, &c->boxes, &c->mats, &c->nodes, &c->tris}) {
         if (b->raw) hipFree(b->raw);
         if (b->packed) hipFree(b->packed);
     }
-    for (void *p : {(void *)c->sample, (void *)c->acc, (void *)c->sum, (void *)c->aux, (void *)c->counters,
+    for (void *p : {(void *)c->sample, (void *)c->sample2, (void *)c->acc, (void *)c->sum, (void *)c->sum2,
+                    (void *)c->aux, (void *)c->counters,
                     (void *)c->q.rays[0], (void *)c->q.hits, (void *)c->q.paths})
         if (p) hipFree(p);
     for (hipEvent_t e : c->ev_trace) hipEventDestroy(e);
     hipEventDestroy(c->ev_begin);
     hipEventDestroy(c->ev_end);
+    hipEventDestroy(c->ev_ready);
+    for (int b = 0; b < 2; b++) {
+        hipEventDestroy(c->ev_tdone[b]);
+        hipEventDestroy(c->ev_acc[b]);
+        hipStreamDestroy(c->tstream[b]);
+    }
     hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -305,7 +390,7 @@ int rt_resize(rt_ctx *c, int width, int height) {
     if (width <= 0 || height <= 0) return fail("rt_resize: size must be positive");
     if ((size_t)width * (size_t)height > ((size_t)1 << 28)) return fail("rt_resize: image too large");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = sync_all(c)) return rc;
     c->W = width;
     c->H = height;
     return alloc_images(c);
@@ -320,7 +405,7 @@ int rt_upload(rt_ctx *c, int binding, const void *data, size_t nbytes) {
     if (nbytes % (size_t)stride) return fail("rt_upload: size is not a multiple of the element stride");
     if (nbytes / (size_t)stride >= ((size_t)1 << 30)) return fail("rt_upload: too many elements");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // the old buffer may still be in use
+    if (int rc = sync_all(c)) return rc;  // the old buffer may still be in use
     if (b->raw) HIP_TRY(hipFree(b->raw));
     b->raw = nullptr;
     b->raw_bytes = nbytes;
@@ -357,6 +442,10 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounces, 
     fill_params(c, &p);
     size_t npix = (size_t)c->W * c->H;
     const bool aux = flags & RT_FLAG_AUX, stats = flags & RT_FLAG_STATS;
+    // frames that write the per-pixel record, and the wavefront pipeline (one ray queue), run one at a time
+    const bool serial = !c->overlap || aux || c->pipeline != 0;
+    if (c->tpending[0] || c->tpending[1] || c->sum2_dirty)
+        if (int rc = join(c)) return rc;  // sum-mode frames still in flight
     if (aux && !c->aux) {
         HIP_TRY(hipMalloc((void **)&c->aux, npix * 16 * sizeof(uint32_t)));
     }
@@ -366,11 +455,25 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounces, 
     if (int rc = begin_timed(c)) return rc;
     for (uint32_t i = 0; i < nframes; i++) {
         p.time = (float)(first_frame + i);  // renderer.py:211 float(self._frames)
-        if (int rc = trace_event(c)) return rc;
-        trace_frame(c, p, 0, aux, stats);
+        const int b = c->flip;
+        c->flip ^= 1;
+        p.sample = b ? c->sample2 : c->sample;
+        hipStream_t ts;
+        if (int rc = trace_stream(c, b, serial, &ts)) return rc;
+        // the accumulate pass that last read this sample image must be done before it is rewritten
+        if (ts != c->stream && c->acc_recorded[b]) HIP_TRY(hipStreamWaitEvent(ts, c->ev_acc[b], 0));
+        if (int rc = trace_event(c, ts)) return rc;
+        trace_frame(c, p, 0, aux, stats, ts);
         c->pixel_samples += (uint64_t)p.WW * (uint64_t)p.HH;
-        if (int rc = trace_event(c)) return rc;
-        rt::launch_accumulate(c->sample, c->acc, npix, (float)c->rendered_frames, c->stream);
+        if (int rc = trace_event(c, ts)) return rc;
+        if (ts != c->stream) {
+            HIP_TRY(hipEventRecord(c->ev_tdone[b], ts));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_tdone[b], 0));
+        }
+        rt::launch_accumulate(p.sample, c->acc, npix, (float)c->rendered_frames, c->stream);
+        HIP_TRY(hipEventRecord(c->ev_acc[b], c->stream));
+        c->acc_recorded[b] = true;
+        c->last_sample = b;
         c->rendered_frames++;
     }
     HIP_TRY(hipGetLastError());
@@ -380,8 +483,11 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounces, 
 int rt_reset_accumulation(rt_ctx *c) {
     if (!c) return fail("rt_reset_accumulation: null context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(c->acc, c->sample, (size_t)c->W * c->H * sizeof(float4), hipMemcpyDeviceToDevice,
-                           c->stream));
+    if (int rc = join(c)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->acc, c->last_sample ? c->sample2 : c->sample, (size_t)c->W * c->H * sizeof(float4),
+                           hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_acc[c->last_sample], c->stream));
+    c->acc_recorded[c->last_sample] = true;
     c->rendered_frames = 0;
     return 0;
 }
@@ -396,13 +502,14 @@ static int read_image(rt_ctx *c, const void *dev, void *host, size_t bytes, cons
     if (!c || !host) return fail(std::string(what) + ": null argument");
     if (!dev) return fail(std::string(what) + ": nothing has been rendered into that buffer");
     HIP_TRY(hipSetDevice(c->device));
+    if (int rc = join(c)) return rc;
     HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 
 int rt_read_sample(rt_ctx *c, float *rgba) {
-    return read_image(c, c ? c->sample : nullptr, rgba, c ? (size_t)c->W * c->H * 16 : 0, "rt_read_sample");
+    return read_image(c, c ? (c->last_sample ? c->sample2 : c->sample) : nullptr, rgba, c ? (size_t)c->W * c->H * 16 : 0, "rt_read_sample");
 }
 int rt_read_accumulation(rt_ctx *c, float *rgba) {
     return read_image(c, c ? c->acc : nullptr, rgba, c ? (size_t)c->W * c->H * 16 : 0, "rt_read_accumulation");
@@ -414,14 +521,14 @@ int rt_read_aux(rt_ctx *c, uint32_t *aux16) {
 int rt_sync(rt_ctx *c) {
     if (!c) return fail("rt_sync: null context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
+    return sync_all(c);
 }
 
 int rt_get_stats(rt_ctx *c, rt_stats *out) {
     if (!c || !out) return fail("rt_get_stats: null argument");
     HIP_TRY(hipSetDevice(c->device));
     rt::Counters hs[rt::kCounterStripes];
+    if (int rc = join(c)) return rc;
     HIP_TRY(hipMemcpyAsync(hs, c->counters, sizeof hs, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memset(out, 0, sizeof *out);
@@ -455,6 +562,8 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
 int rt_reset_stats(rt_ctx *c) {
     if (!c) return fail("rt_reset_stats: null context");
     HIP_TRY(hipSetDevice(c->device));
+    if (int rc = join(c)) return rc;
+    c->main_dirty = true;
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(rt::Counters) * rt::kCounterStripes, c->stream));
     c->pixel_samples = 0;
     return 0;
@@ -470,18 +579,35 @@ int rt_render_sum(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounc
     if (int rc = prepare_scene(c, &p.scene)) return rc;
     fill_params(c, &p);
     p.sample = nullptr;
-    p.sum = sum_rgba ? reinterpret_cast<float4 *>(sum_rgba) : c->sum;
+    float4 *target = sum_rgba ? reinterpret_cast<float4 *>(sum_rgba) : c->sum;
     p.shard = shard;
     p.nshards = nshards;
     p.bounces = bounces;
     const uint64_t owned = owned_pixels(p.WW, p.HH, shard, nshards);
+    const bool serial = !c->overlap || c->pipeline != 0;
+    // odd frames are summed in a second image and folded into the target by the next join; a
+    // different target starts a new pair
+    if (c->sum2_dirty && c->sum2_target != target)
+        if (int rc = join(c)) return rc;
     if (int rc = begin_timed(c)) return rc;
     for (uint32_t i = frame_phase; i < nframes; i += frame_stride) {
         p.time = (float)(first_frame + i);
-        if (int rc = trace_event(c)) return rc;
-        trace_frame(c, p, 1, false, false);
+        const int b = serial ? 0 : c->flip;
+        if (!serial) c->flip ^= 1;
+        hipStream_t ts;
+        if (int rc = trace_stream(c, b, serial, &ts)) return rc;
+        p.sum = (b && !serial) ? c->sum2 : target;
+        if (int rc = trace_event(c, ts)) return rc;
+        trace_frame(c, p, 1, false, false, ts);
         c->pixel_samples += owned;
-        if (int rc = trace_event(c)) return rc;
+        if (int rc = trace_event(c, ts)) return rc;
+        if (ts != c->stream) {
+            c->tpending[b] = true;
+            if (b) {
+                c->sum2_dirty = true;
+                c->sum2_target = target;
+            }
+        }
     }
     HIP_TRY(hipGetLastError());
     return end_timed(c);
@@ -497,6 +623,9 @@ int rt_sum_buffer(rt_ctx *c, float **device_ptr, size_t *nbytes) {
 int rt_clear_sum(rt_ctx *c, float *sum_rgba) {
     if (!c) return fail("rt_clear_sum: null context");
     HIP_TRY(hipSetDevice(c->device));
+    if (int rc = join(c)) return rc;
+    c->main_dirty = true;
+    c->flip = 0;  // the launch after a clear adds into the sum image itself, the one after it into the second image
     HIP_TRY(hipMemsetAsync(sum_rgba ? (void *)sum_rgba : (void *)c->sum, 0, (size_t)c->W * c->H * sizeof(float4),
                            c->stream));
     return 0;
@@ -506,6 +635,7 @@ int rt_finalize_sum(rt_ctx *c, const float *sum_rgba, uint32_t spp) {
     if (!c) return fail("rt_finalize_sum: null context");
     if (spp == 0) return fail("rt_finalize_sum: spp must be positive");
     HIP_TRY(hipSetDevice(c->device));
+    if (int rc = join(c)) return rc;
     rt::launch_finalize_sum(sum_rgba ? reinterpret_cast<const float4 *>(sum_rgba) : c->sum, c->acc,
                             (size_t)c->W * c->H, spp, c->stream);
     HIP_TRY(hipGetLastError());

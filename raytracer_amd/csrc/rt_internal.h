@@ -83,6 +83,7 @@ void launch_wavefront_frame(const TraceParams &p, const WaveQueues &q, int mode,
 // accumulate pass: acc = srgb(lin(acc) + (lin(sample) - lin(acc)) / (frames + 1))
 void launch_accumulate(const float4 *sample, float4 *acc, size_t npixels, float frames, hipStream_t s);
 // acc = srgb(sum / spp)
+void launch_fold_sum(float4 *target, float4 *part, size_t npixels, hipStream_t s);
 void launch_finalize_sum(const float4 *sum, float4 *acc, size_t npixels, uint32_t spp, hipStream_t s);
 
 }  // namespace rt

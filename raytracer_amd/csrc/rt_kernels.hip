@@ -1320,6 +1320,18 @@ __global__ void finalize_sum_kernel(const float4 *__restrict__ sum, float4 *__re
     acc[i] = make_float4(l2s(s.x / spp), l2s(s.y / spp), l2s(s.z / spp), 1.0f);
 }
 
+// target += part; part = 0
+__global__ void fold_sum_kernel(float4 *__restrict__ target, float4 *__restrict__ part, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 t = target[i], s = part[i];
+    target[i] = make_float4(t.x + s.x, t.y + s.y, t.z + s.z, t.w + s.w);
+    part[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+void launch_fold_sum(float4 *target, float4 *part, size_t npixels, hipStream_t s) {
+    hipLaunchKernelGGL(fold_sum_kernel, dim3((unsigned)((npixels + 255) / 256)), dim3(256), 0, s, target, part, npixels);
+}
+
 void launch_accumulate(const float4 *sample, float4 *acc, size_t npixels, float frames, hipStream_t s) {
     hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((npixels + 255) / 256)), dim3(256), 0, s, sample, acc,
                        npixels, frames);
