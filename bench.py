@@ -216,7 +216,9 @@ def main():
         if tj.exists():
             t = json.loads(tj.read_text())
             if t.get("workload_key") == key:
-                traffic = (t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
+                # FETCH_SIZE tallies a 128-byte line request as 64 B on gfx950 (calibrated for this
+                # access pattern with tools/microbench/fetch_calib.hip), hence the correction factor
+                traffic = (t["fetch_size_kb"] * t.get("fetch_correction", 2.0) + t["write_size_kb"]) * 1024.0
         out = {
             "metric": "Mrays/s", "value": total_rays / elapsed_max / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
