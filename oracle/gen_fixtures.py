@@ -302,6 +302,32 @@ def main():
         golden_frames(s, "mid_640x360_b4", 640, 360, 4, 0, 3, T, store_full=False, kinds=("color", "primary", "counters"))
         golden_state(s, "state_160x88_b4_f1", 160, 88, 4, 1, T)
         golden_accumulation(s, "accum_160x88_b4", 160, 88, 4, 6, T)
+    if want("oob"):
+        # gally with damaged indices: some leaves point past the triangle buffer, some inner
+        # children past the node buffer.  GL robust buffer access makes such reads return zeros;
+        # the product clamps them to an all-zero record.  No cycles are introduced.
+        src = GOLD / "gally"
+        s = GOLD / "gally_oob"
+        s.mkdir(exist_ok=True)
+        for f in ("mats.bin", "spheres.bin", "tris.bin", "uniforms.bin"):
+            (s / f).write_bytes((src / f).read_bytes())
+        bvh = np.frombuffer((src / "bvh.bin").read_bytes(), dtype=np.uint32).reshape(-1, 16).copy()
+        n_nodes = bvh.shape[0]
+        n_tris = (src / "tris.bin").stat().st_size // 64
+        rng = np.random.default_rng(7)
+        meta = bvh[:, 12:16]
+        typ, idx = meta >> 30, meta & 0x3FFFFFFF
+        leaf = np.argwhere(typ == 0)
+        for r, c in leaf[rng.choice(len(leaf), size=len(leaf) // 25, replace=False)]:
+            meta[r, c] = (0 << 30) | (n_tris + int(rng.integers(0, 1 << 20)))
+        inner = np.argwhere((typ == 3) & (idx < n_nodes) & (np.arange(n_nodes)[:, None] > 20))
+        for r, c in inner[rng.choice(len(inner), size=len(inner) // 40, replace=False)]:
+            meta[r, c] = (3 << 30) | (n_nodes + int(rng.integers(0, 1 << 16)))
+        (s / "bvh.bin").write_bytes(bvh.tobytes())
+        (s / "meta.json").write_text(json.dumps({"name": "gally_oob", "derived_from": "gally", "damaged_leaves":
+                                                 len(leaf) // 25, "damaged_inner": len(inner) // 40}, indent=1))
+        golden_frames(s, "small_160x88_b4", 160, 88, 4, 0, 2, T, store_full=True, kinds=("color", "primary"))
+        golden_frames(s, "mid_640x360_b4", 640, 360, 4, 0, 2, T, store_full=False, kinds=("color", "primary"))
     if want("configs"):
         # the full-size single-GPU configurations: per-frame hashes of every sample image, and of the
         # running mean after every frame (hash only; nothing of this size is stored whole)
