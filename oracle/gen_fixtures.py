@@ -353,6 +353,35 @@ def main():
              "frames": [0, 16], "sample_sha256_per_frame": [sha(img[i]) for i in range(16)],
              "acc_sha256_per_frame": [sha(acc[i]) for i in range(16)], "llvmpipe_ms": info["ms"], "threads": T},
             indent=1))
+    if want("sponza"):
+        # the bench workload itself (configuration C4 with the stand-in scene): hashes of the reference
+        # shader's 1080p output and its llvmpipe frame time; the 25 MB of buffers are not stored
+        # (tests rebuild them with the host pipeline, whose byte parity "big" pins)
+        from raytracer_amd import synth
+        scene, meshes = synth.sponza_synth(1.0)
+        from raytracer_amd import scene as S
+        b = S.build_scene(scene, extra_meshes=meshes, sequential_mesh_indices=True)
+        with tempfile.TemporaryDirectory(prefix="rtc4_") as td:
+            td = Path(td)
+            (td / "mats.bin").write_bytes(b.materials.tobytes())
+            (td / "spheres.bin").write_bytes(b.spheres.tobytes())
+            (td / "tris.bin").write_bytes(b.triangles.tobytes())
+            (td / "bvh.bin").write_bytes(b.bvh.tobytes())
+            inv_vp, eye = Camera().uniforms_f32()
+            np.concatenate([inv_vp, eye, b.scene_min, b.scene_extent]).astype(np.float32).tofile(td / "uniforms.bin")
+            rec = {"scene": "sponza_synth(detail=1.0), sequential mesh indices, default camera", "w": 1920, "h": 1080,
+                   "bounces": 4, "frames": [0, 3], "buffers_sha256": {"mats": sha(b.materials), "spheres": sha(b.spheres),
+                                                                     "tris": sha(b.triangles), "bvh": sha(b.bvh)}}
+            img, info = run_shader("color", td, 1920, 1080, 4, 0, 3, T)
+            rec["sample_sha256_per_frame"] = [sha(img[i]) for i in range(3)]
+            rec["llvmpipe_ms"] = info["ms"]
+            rec["threads"] = T
+            prim, _ = run_shader("primary", td, 1920, 1080, 4, 0, 1, T)
+            code, tbits, exists = __import__("oracle").primary_from_golden(prim[0])
+            rec["primary_sha256"] = {"code": sha(code), "t_bits": sha(tbits), "exists": sha(exists)}
+            cnt, _ = run_shader("counters", td, 1920, 1080, 4, 0, 1, T)
+            rec["rays_frame0"] = int((cnt[0, :, :, 3].astype(np.int64) // 64).sum())
+        (GOLD / "c4_sponza_synth_1920x1080_b4.json").write_text(json.dumps(rec, indent=1))
     if want("big"):
         # byte-level pins for the native scene pipeline on large inputs: only hashes are kept
         from raytracer_amd import synth

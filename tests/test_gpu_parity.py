@@ -167,6 +167,32 @@ def test_sphere_obj_configuration_all_frames(renderer):
         assert sha(renderer.read_accumulation()) == rec["acc_sha256_per_frame"][f], f"running mean after {f}"
 
 
+def test_bench_workload_matches_reference_shader(renderer):
+    """sponza_synth at 1920x1080, 4 bounces -- what bench.py times -- against the reference
+    shader's hashes: three sample images, first-hit ids and distances of frame 0, ray count."""
+    from raytracer_amd import scene as S, synth
+    from raytracer_amd.camera import Camera
+
+    rec = json.loads((GOLDEN / "c4_sponza_synth_1920x1080_b4.json").read_text())
+    scene, meshes = synth.sponza_synth(1.0)
+    S.build_scene(scene, extra_meshes=meshes, sequential_mesh_indices=True).upload(renderer)
+    inv_vp, eye = Camera().uniforms_f32()
+    renderer.set_uniforms(inv_vp, eye)
+    w, h, b = rec["w"], rec["h"], rec["bounces"]
+    renderer.reset_stats()
+    render_frame(renderer, w, h, 0, b, aux=True)
+    assert sha(renderer.read_sample()) == rec["sample_sha256_per_frame"][0]
+    aux = renderer.read_aux()
+    assert sha(aux[..., 0]) == rec["primary_sha256"]["code"]
+    assert sha(aux[..., 1]) == rec["primary_sha256"]["t_bits"]
+    assert sha(aux[..., 2]) == rec["primary_sha256"]["exists"]
+    # the counter-instrumented shader variant compiles slightly differently in rare pixels
+    assert abs(renderer.stats()["rays"] - rec["rays_frame0"]) <= 1e-5 * rec["rays_frame0"]
+    for f in (1, 2):
+        render_frame(renderer, w, h, f, b)
+        assert sha(renderer.read_sample()) == rec["sample_sha256_per_frame"][f], f"frame {f}"
+
+
 def test_edge_sizes_and_truncated_dispatch(renderer):
     """Sizes that are not multiples of 8x4 leave the edge pixels unwritten, as the reference's
     glDispatchCompute(int(W/8), int(H/4), 1) does."""

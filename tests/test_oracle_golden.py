@@ -169,3 +169,26 @@ def test_sphere_obj_configuration_first_frames():
         assert sha(s) == rec["sample_sha256_per_frame"][f]
         acc = O.accumulate(s, acc, f)
         assert sha(acc) == rec["acc_sha256_per_frame"][f]
+
+
+def test_bench_workload_first_frame():
+    """sponza_synth (265 k triangles) at 1920x1080, 4 bounces -- the bench workload -- against the
+    reference shader's hashes: colour image, first-hit primitive ids and distances of frame 0."""
+    from raytracer_amd import scene as S, synth
+    from raytracer_amd.camera import Camera
+
+    rec = json.loads((GOLDEN / "c4_sponza_synth_1920x1080_b4.json").read_text())
+    scene, meshes = synth.sponza_synth(1.0)
+    b = S.build_scene(scene, extra_meshes=meshes, sequential_mesh_indices=True)
+    assert sha(b.bvh) == rec["buffers_sha256"]["bvh"] and sha(b.triangles) == rec["buffers_sha256"]["tris"]
+    inv_vp, eye = Camera().uniforms_f32()
+    sc = O.OracleScene(bvh=b.bvh.tobytes(), tris=b.triangles.tobytes(), spheres=b.spheres.tobytes(),
+                       mats=b.materials.tobytes(),
+                       uniforms=np.concatenate([inv_vp, eye, b.scene_min, b.scene_extent]))
+    img, aux, cnt = sc.render(rec["w"], rec["h"], 0, rec["bounces"], want_primary=True, want_counters=True)
+    assert sha(img) == rec["sample_sha256_per_frame"][0]
+    assert sha(aux[..., 0]) == rec["primary_sha256"]["code"]
+    assert sha(aux[..., 1]) == rec["primary_sha256"]["t_bits"]
+    assert sha(aux[..., 2]) == rec["primary_sha256"]["exists"]
+    # the counter-instrumented shader variant compiles slightly differently in rare pixels
+    assert abs(cnt["rays"] - rec["rays_frame0"]) <= 1e-5 * rec["rays_frame0"]
