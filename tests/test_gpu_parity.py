@@ -334,6 +334,52 @@ def test_sum_mode_two_frames_in_flight_is_deterministic(renderer):
         assert np.array_equal(got.view(np.uint32), expect.view(np.uint32)), chunks
 
 
+def test_interactive_hooks_reset_the_running_mean(renderer):
+    """The app loop's hooks (controller.py:124-128,218-219, window.py:199, renderer.py:170-173): a
+    camera change, a bounce-count change followed by reset_accumulation, and a resize all restart
+    the running mean; the frame counter that feeds `time` keeps counting."""
+    load_golden_scene(renderer, "debug")
+    w, h = 160, 88
+    renderer.update_size(w, h)
+    renderer.bounces = 2
+    renderer.set_frame_index(0)
+    renderer.camera.changed = False
+    for _ in range(3):
+        renderer.render()
+    assert renderer.rendered_frames == 3
+    mean3 = renderer.read_accumulation()
+    assert not np.array_equal(mean3, renderer.read_sample())
+    # camera moved: the next render() resets first (the old sample becomes the mean, count 0), so
+    # the new mean is the accumulate pass of that one frame with weight 1
+    sc = O.OracleScene.from_dir(GOLDEN / "debug")
+    renderer.camera.changed = True
+    renderer.render()
+    assert renderer.rendered_frames == 1
+    s3 = sc.render(w, h, 3, 2)  # `time` went on to 3
+    assert np.array_equal(renderer.read_sample(), s3)
+    assert np.array_equal(renderer.read_accumulation(), O.accumulate(s3, sc.render(w, h, 2, 2), 0))
+    # bounces changed by the controller, which then resets
+    renderer.render()
+    renderer.bounces = 3
+    renderer.reset_accumulation()
+    assert renderer.rendered_frames == 0
+    assert np.array_equal(renderer.read_accumulation(), sc.render(w, h, 4, 2))
+    renderer.render()
+    s5 = sc.render(w, h, 5, 3)
+    assert np.array_equal(renderer.read_sample(), s5)
+    assert np.array_equal(renderer.read_accumulation(), O.accumulate(s5, sc.render(w, h, 4, 2), 0))
+    # resize: fresh (zero) images
+    renderer.render()
+    renderer.update_size(w + 16, h + 8)
+    assert renderer.rendered_frames == 0 and (renderer.width, renderer.height) == (w + 16, h + 8)
+    renderer.render()
+    s7 = sc.render(w + 16, h + 8, 7, 3)
+    assert np.array_equal(renderer.read_sample(), s7)
+    assert np.array_equal(renderer.read_accumulation(), O.accumulate(s7, np.zeros_like(s7), 0))
+    with pytest.raises(TypeError):
+        renderer.bounces = -1
+
+
 def test_error_reporting(renderer):
     with pytest.raises(ValueError):
         renderer.update_ssbo(0, np.zeros(64, np.uint8), 13)

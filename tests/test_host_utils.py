@@ -1,0 +1,67 @@
+"""Host-side pieces around the render path that need no GPU: the PNG consumer of the accumulation
+image and the camera controls that trigger an accumulation reset."""
+
+import struct
+import zlib
+
+import numpy as np
+
+from raytracer_amd import png
+from raytracer_amd.camera import Camera
+
+
+def _decode_png(path):
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, {}
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert crc == zlib.crc32(tag + body) & 0xFFFFFFFF
+        chunks.setdefault(tag, b"")
+        chunks[tag] += body
+        pos += 12 + n
+    w, h, depth, ctype = struct.unpack(">IIBB", chunks[b"IHDR"][:10])
+    assert (depth, ctype) == (8, 2)
+    raw = zlib.decompress(chunks[b"IDAT"])
+    rows = np.frombuffer(raw, np.uint8).reshape(h, 1 + 3 * w)
+    assert np.all(rows[:, 0] == 0)  # filter type none
+    return rows[:, 1:].reshape(h, w, 3)
+
+
+def test_png_is_clipped_quantised_and_upright(tmp_path):
+    h, w = 5, 7
+    img = np.zeros((h, w, 4), np.float32)
+    img[0, :, 0] = 1.0           # bottom row of the GL image: red
+    img[h - 1, :, 2] = 2.5       # top row: blue, beyond 1 (the accumulation image is unclamped)
+    img[2, 3, :3] = [0.5, -1.0, np.nan]
+    img[..., 3] = 1.0
+    p = tmp_path / "a.png"
+    png.save_png(p, img)
+    out = _decode_png(p)
+    assert out.shape == (h, w, 3)
+    assert np.all(out[h - 1, :, 0] == 255) and np.all(out[h - 1, :, 1:] == 0)  # red row ends up at the bottom of the file
+    assert np.all(out[0, :, 2] == 255)
+    assert tuple(out[h - 1 - 2, 3]) == (128, 0, 0)
+
+
+def test_camera_controls_flag_a_change_and_move_as_the_reference_does():
+    c = Camera()
+    c.changed = False
+    inv0, eye0 = c.uniforms_f32()
+    c.forward(0.5)
+    assert c.changed
+    _, eye1 = c.uniforms_f32()
+    np.testing.assert_allclose(eye1 - eye0, np.float32(0.5) * c.front.astype(np.float32), atol=1e-6)
+    c.changed = False
+    c.turn(100.0, 2000.0)        # pitch is clamped to +-89 degrees (camera.py:129-141)
+    assert c.changed and c.pitch == 89.0 and abs(c.yaw - 190.0) < 1e-9
+    c.turn(0.0, -5000.0)
+    assert c.pitch == -89.0
+    c.changed = False
+    c.strafe(1.0)
+    c.rise(-0.25)
+    assert c.changed
+    inv2, _ = c.uniforms_f32()
+    assert inv2.dtype == np.float32 and inv2.shape == (16,) and not np.array_equal(inv2, inv0)
