@@ -234,7 +234,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": rays_per_launch * bytes_per_ray,
-                         "kernel": "trace_kernel", "kernel_ms": kernel_ms, "bytes_per_ray": bytes_per_ray,
+                         "kernel": "trace_kernel", "kernel_ms": kernel_ms,
+                         "kernel_ms_how": "HIP events on the launch's stream, launches issued one at a time after "
+                                          "the timed region; inside the timed region two launches overlap, so a "
+                                          "kernel trace of this command shows longer per-kernel durations "
+                                          "(RT_OVERLAP=0 gives matching ones)",
+                         "bytes_per_ray": bytes_per_ray,
                          "per_ray": {"node_visits": n_node, "triangle_tests": n_tri, "sphere_tests": n_sph,
                                      "hit_fraction": hit_frac, "rays_per_pixel_sample": rays_per_sample}},
         }
