@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE — random scenes pinned against the reference shader (build container only).
+
+Draws small random scenes in the reference's TOML schema (spheres, quads, boxes, planes, materials
+over their whole parameter ranges, cameras placed anywhere including inside objects), builds their
+buffers with the reference's own classes, renders them with the reference's compute.glsl on
+llvmpipe and stores, per case, the scene description, the 25 uniform words and the image hashes
+(plus the small images of the first frame) in tests/golden/fuzz/.  The tests rebuild the buffers
+with the host pipeline and compare oracle and HIP output against these.
+
+  python oracle/gen_fuzz.py [--cases N] [--seed S]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle"))
+
+import gen_fixtures as G  # noqa: E402
+import refscene  # noqa: E402
+from raytracer_amd.camera import Camera  # noqa: E402
+
+OUT = G.GOLD / "fuzz"
+W, H = 96, 64
+
+
+def r3(rng, lo, hi):
+    return [round(float(x), 3) for x in rng.uniform(lo, hi, 3)]
+
+
+def random_scene(rng: np.random.Generator, case: int) -> tuple[dict, dict]:
+    mats = [{"color": [1.0, 1.0, 1.0], "emission": [1.0, 1.0, 1.0, float(rng.integers(2, 20))]}]
+    for _ in range(int(rng.integers(3, 9))):
+        m = {"color": r3(rng, 0.0, 1.0)}
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            m["emission"] = r3(rng, 0.0, 1.0) + [float(rng.integers(0, 300))]
+        # the whole range, and values outside it (the packer clamps): smoothness 1 = mirror branch
+        m["smoothness"] = float(rng.choice([0.0, 1.0, round(float(rng.uniform(-0.2, 1.2)), 3)]))
+        m["metallic"] = float(rng.choice([0.0, 1.0, round(float(rng.uniform(0, 1)), 3)]))
+        m["transmission"] = float(rng.choice([0.0, 1.0, round(float(rng.uniform(0, 1)), 3)]))
+        m["ior"] = float(rng.choice([1.0, 1.5, round(float(rng.uniform(0.0, 3.5)), 3)]))
+        mats.append(m)
+    nm = len(mats)
+    scene = {"title": f"fuzz {case}", "materials": mats, "spheres": [], "quads": [], "boxes": [], "planes": []}
+    for _ in range(int(rng.integers(1, 10))):
+        scene["spheres"].append({"center": r3(rng, -4, 4), "radius": round(float(rng.uniform(0.05, 1.5)), 3),
+                                 "material": int(rng.integers(0, nm))})
+    for _ in range(int(rng.integers(1, 8))):
+        n = rng.normal(size=3)
+        if rng.random() < 0.5:  # axis-aligned walls are the common case and the degenerate one for the slab test
+            n = np.eye(3)[rng.integers(0, 3)] * rng.choice([-1.0, 1.0])
+        scene["quads"].append({"center": r3(rng, -5, 5), "width": round(float(rng.uniform(0.5, 12)), 2),
+                               "height": round(float(rng.uniform(0.5, 12)), 2), "normal": [float(x) for x in n],
+                               "material": int(rng.integers(0, nm))})
+    for _ in range(int(rng.integers(0, 5))):
+        p0 = np.array(r3(rng, -4, 4))
+        scene["boxes"].append({"p0": [float(x) for x in p0], "p1": [float(x) for x in p0 + rng.uniform(-2, 2, 3).round(3)],
+                               "material": int(rng.integers(0, nm))})
+    for _ in range(int(rng.integers(0, 3))):
+        n = np.eye(3)[rng.integers(0, 3)] * rng.choice([-1.0, 1.0]) if rng.random() < 0.7 else rng.normal(size=3)
+        n = n / np.linalg.norm(n)
+        scene["planes"].append({"point": r3(rng, -6, 6), "normal": [float(x) for x in n], "material": int(rng.integers(0, nm))})
+    if rng.random() < 0.6:  # an emissive shell around everything, so that most paths end lit
+        scene["spheres"].append({"center": [0.0, 0.0, 0.0], "radius": 40.0, "material": 0})
+    cam = {"position": r3(rng, -6, 6), "yaw": float(rng.choice([0.0, 90.0, 180.0, 270.0, round(float(rng.uniform(0, 360)), 2)])),
+           "pitch": float(rng.choice([0.0, round(float(rng.uniform(-80, 80)), 2)]))}
+    if rng.random() < 0.25 and scene["spheres"]:  # eye inside a sphere
+        cam["position"] = [float(x) for x in scene["spheres"][0]["center"]]
+    return scene, cam
+
+
+def camera_uniforms(cam: dict):
+    c = Camera()
+    c.position = np.array(cam["position"], dtype=np.float64)
+    c.yaw, c.pitch = cam["yaw"], cam["pitch"]
+    c._update_camera_vectors()
+    return c.uniforms_f32()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=24)
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--threads", type=int, default=8)
+    args = ap.parse_args()
+    OUT.mkdir(parents=True, exist_ok=True)
+    rng = np.random.default_rng(args.seed)
+    firsts = {}
+    for case in range(args.cases):
+        scene, cam = random_scene(rng, case)
+        b = refscene.build_reference_scene(scene, [])
+        inv_vp, eye = camera_uniforms(cam)
+        uni = np.concatenate([inv_vp, eye, b["scene_min"], b["scene_extent"]]).astype(np.float32)
+        bounces = int(rng.integers(2, 9))
+        with tempfile.TemporaryDirectory(prefix="rtfuzz_") as td:
+            td = Path(td)
+            for key in ("mats", "spheres", "tris", "bvh", "boxes", "planes"):
+                (td / f"{key}.bin").write_bytes(b[key])
+            uni.tofile(td / "uniforms.bin")
+            img, _ = G.run_shader("color", td, W, H, bounces, 0, 3, args.threads)
+            prim, _ = G.run_shader("primary", td, W, H, bounces, 0, 1, args.threads)
+        rec = {"scene": scene, "camera": cam, "uniform_words": ["%08x" % x for x in uni.view(np.uint32)],
+               "w": W, "h": H, "bounces": bounces, "frames": [0, 3],
+               "buffers_sha256": {k: G.sha(b[k]) for k in ("mats", "spheres", "tris", "bvh", "boxes", "planes")},
+               "sample_sha256_per_frame": [G.sha(img[i]) for i in range(3)],
+               "lit_fraction": float((img[0, :, :, :3].sum(-1) > 0).mean())}
+        (OUT / f"case{case:02d}.json").write_text(json.dumps(rec, indent=1))
+        firsts[f"color{case:02d}"] = img[0]
+        firsts[f"primary{case:02d}"] = prim[0]
+        print(case, bounces, "lit", round(rec["lit_fraction"], 3), flush=True)
+    np.savez_compressed(OUT / "first_frames.npz", **firsts)
+
+
+if __name__ == "__main__":
+    main()

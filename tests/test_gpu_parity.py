@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def _cases():
     out = []
-    for sdir in sorted(p for p in GOLDEN.iterdir() if p.is_dir()):
+    for sdir in sorted(p for p in GOLDEN.iterdir() if p.is_dir() and p.name != "fuzz"):
         for j in sorted(sdir.glob("*.json")):
             if j.name in ("meta.json", "scene.json") or j.name.endswith((".state.json", ".acc.json")):
                 continue
@@ -191,6 +191,31 @@ def test_bench_workload_matches_reference_shader(renderer):
     for f in (1, 2):
         render_frame(renderer, w, h, f, b)
         assert sha(renderer.read_sample()) == rec["sample_sha256_per_frame"][f], f"frame {f}"
+
+
+def test_random_scenes_match_reference_shader(renderer):
+    """32 random scenes pinned on llvmpipe: colour frames, first-hit ids and distances."""
+    from util import fuzz_buffers, fuzz_cases
+
+    first = np.load(GOLDEN / "fuzz" / "first_frames.npz")
+    bad = []
+    for path in fuzz_cases():
+        rec = json.loads(path.read_text())
+        b, u = fuzz_buffers(rec)
+        b.upload(renderer)
+        renderer.set_uniforms(u[0:16], u[16:19])
+        n = path.stem[4:]
+        for f in range(*rec["frames"]):
+            img = render_frame(renderer, rec["w"], rec["h"], f, rec["bounces"], aux=(f == 0))
+            if sha(img) != rec["sample_sha256_per_frame"][f]:
+                bad.append((path.name, f, "colour"))
+            if f == 0:
+                aux = renderer.read_aux()
+                code, tbits, exists = O.primary_from_golden(first["primary" + n])
+                if not (np.array_equal(code, aux[..., 0]) and np.array_equal(tbits, aux[..., 1])
+                        and np.array_equal(exists, aux[..., 2])):
+                    bad.append((path.name, f, "first hit"))
+    assert not bad, bad
 
 
 def test_edge_sizes_and_truncated_dispatch(renderer):

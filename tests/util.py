@@ -37,3 +37,20 @@ def render_frame(renderer, w, h, frame, bounces, aux=False, stats=False):
     renderer.camera.changed = False
     renderer.render()
     return renderer.read_sample()
+
+
+def fuzz_cases():
+    return sorted((GOLDEN / "fuzz").glob("case*.json"))
+
+
+def fuzz_buffers(rec):
+    """Buffers of a random scene rebuilt by the host pipeline, checked against the hashes of the
+    buffers the reference's own classes produced; returns (SceneBuffers, 25 uniform floats)."""
+    from raytracer_amd import scene as S
+
+    b = S.build_scene(rec["scene"])
+    for key, arr in (("mats", b.materials), ("spheres", b.spheres), ("tris", b.triangles), ("bvh", b.bvh),
+                     ("boxes", b.boxes), ("planes", b.planes)):
+        assert sha(arr) == rec["buffers_sha256"][key], key
+    u = np.array([int(x, 16) for x in rec["uniform_words"]], dtype=np.uint32).view(np.float32)
+    return b, u
