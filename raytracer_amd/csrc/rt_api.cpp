@@ -36,6 +36,33 @@ struct RawBuffer {           // device copy of an uploaded reference-layout buff
     bool dirty = true;        // packed is stale
 };
 
+// Breadth-first order of the node graph from node 0: order[new] = old, rank[old] = new.  Every
+// node appears exactly once (nodes the root does not reach keep their relative order at the end;
+// a child index is followed only the first time it is met, so malformed graphs are fine).
+void breadth_first_order(const uint32_t *nodes, uint32_t n, std::vector<uint32_t> &order, std::vector<uint32_t> &rank) {
+    order.clear();
+    order.reserve(n);
+    rank.assign(n, 0xFFFFFFFFu);
+    if (n == 0) return;
+    rank[0] = 0;
+    order.push_back(0);
+    for (size_t head = 0; head < order.size(); head++) {
+        const uint32_t *meta = nodes + (size_t)order[head] * 16 + 12;
+        for (int k = 0; k < 4; k++) {
+            const uint32_t idx = meta[k] & 0x3FFFFFFFu;
+            if ((meta[k] >> 30) == 3u && idx < n && rank[idx] == 0xFFFFFFFFu) {
+                rank[idx] = (uint32_t)order.size();
+                order.push_back(idx);
+            }
+        }
+    }
+    for (uint32_t i = 0; i < n; i++)
+        if (rank[i] == 0xFFFFFFFFu) {
+            rank[i] = (uint32_t)order.size();
+            order.push_back(i);
+        }
+}
+
 }  // namespace
 
 struct rt_ctx {
@@ -43,6 +70,9 @@ struct rt_ctx {
     hipStream_t stream = nullptr;
     int W = 1280, H = 720;
     RawBuffer spheres, planes, boxes, mats, nodes, tris;
+    uint32_t *node_order = nullptr, *node_rank = nullptr;  // device: breadth-first renumbering of the nodes
+    size_t node_perm_cap = 0;
+    std::vector<uint32_t> host_nodes;                       // host copy of the uploaded node words (for the renumbering)
     float smin[3] = {0, 0, 0}, sext[3] = {0, 0, 0};
     float inv_vp[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     float eye[3] = {0, 0, 0};
@@ -215,7 +245,26 @@ int repack(rt_ctx *c, int binding) {
         b->packed_cap = need;
     }
     switch (binding) {
-        case RT_BINDING_BVH: rt::launch_repack_nodes(b->raw, b->count, c->smin, c->sext, b->packed, c->stream); break;
+        case RT_BINDING_BVH: {
+            std::vector<uint32_t> order, rank;
+            breadth_first_order(c->host_nodes.data(), b->count, order, rank);
+            if ((size_t)b->count + 1 > c->node_perm_cap) {
+                if (c->node_order) HIP_TRY(hipFree(c->node_order));
+                if (c->node_rank) HIP_TRY(hipFree(c->node_rank));
+                c->node_order = c->node_rank = nullptr;
+                HIP_TRY(hipMalloc((void **)&c->node_order, ((size_t)b->count + 1) * sizeof(uint32_t)));
+                HIP_TRY(hipMalloc((void **)&c->node_rank, ((size_t)b->count + 1) * sizeof(uint32_t)));
+                c->node_perm_cap = (size_t)b->count + 1;
+            }
+            if (b->count) {
+                HIP_TRY(hipMemcpyAsync(c->node_order, order.data(), (size_t)b->count * 4, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipMemcpyAsync(c->node_rank, rank.data(), (size_t)b->count * 4, hipMemcpyHostToDevice, c->stream));
+                // the vectors die at the end of this block: the copies must have read them by then
+                HIP_TRY(hipStreamSynchronize(c->stream));
+            }
+            rt::launch_repack_nodes(b->raw, b->count, c->smin, c->sext, c->node_order, c->node_rank, b->packed, c->stream);
+            break;
+        }
         case RT_BINDING_TRIANGLES: rt::launch_repack_tris(b->raw, b->count, b->packed, c->stream); break;
         case RT_BINDING_SPHERES: rt::launch_repack_spheres(b->raw, b->count, b->packed, c->stream); break;
         case RT_BINDING_MATERIALS: rt::launch_repack_mats(b->raw, b->count, b->packed, c->stream); break;
@@ -367,7 +416,7 @@ int rt_destroy(rt_ctx *c) {
         if (b->raw) hipFree(b->raw);
         if (b->packed) hipFree(b->packed);
     }
-    for (void *p : {(void *)c->sample, (void *)c->sample2, (void *)c->acc, (void *)c->sum, (void *)c->sum2,
+    for (void *p : {(void *)c->node_order, (void *)c->node_rank, (void *)c->sample, (void *)c->sample2, (void *)c->acc, (void *)c->sum, (void *)c->sum2,
                     (void *)c->aux, (void *)c->counters,
                     (void *)c->q.rays[0], (void *)c->q.hits, (void *)c->q.paths})
         if (p) hipFree(p);
@@ -415,6 +464,7 @@ int rt_upload(rt_ctx *c, int binding, const void *data, size_t nbytes) {
         // the caller's array may be reused as soon as this returns, as with glBufferData
         HIP_TRY(hipMemcpy(b->raw, data, nbytes, hipMemcpyHostToDevice));
     }
+    if (binding == RT_BINDING_BVH) c->host_nodes.assign((const uint32_t *)data, (const uint32_t *)data + nbytes / 4);
     b->dirty = true;
     return 0;
 }

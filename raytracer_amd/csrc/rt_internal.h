@@ -68,8 +68,8 @@ struct WaveQueues {
 };
 
 // repack kernels: reference byte layouts -> device records (n elements + 1 zero-source sentinel)
-void launch_repack_nodes(const uint32_t *src, uint32_t n, const float smin[3], const float sext[3], float4 *dst,
-                         hipStream_t s);
+void launch_repack_nodes(const uint32_t *src, uint32_t n, const float smin[3], const float sext[3],
+                         const uint32_t *order, const uint32_t *rank, float4 *dst, hipStream_t s);
 void launch_repack_tris(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s);
 void launch_repack_spheres(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s);
 void launch_repack_mats(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s);

@@ -48,6 +48,9 @@ namespace rt {
 #ifndef RT_REGTOP
 #define RT_REGTOP 0  // megakernel: keep the next node to visit in a register when the last visit pushed one (measured: no gain)
 #endif
+#ifndef RT_WARM
+#define RT_WARM 0    // with RT_REGTOP: request the next node's cache line before the leaf tests
+#endif
 #ifndef RT_PREFETCH
 #define RT_PREFETCH 0  // megakernel: fetch the next node before intersecting the pending leaves
 #endif
@@ -198,13 +201,25 @@ __device__ __forceinline__ float draw(uint32_t &s) {
 // ------------------------------------------------------------------------------------------
 // BVH node.  RT_NODE64: kept in the reference's 64-byte form (plus the all-zero sentinel).
 // Otherwise decoded once here, compute.glsl:244-261: f = float(q)/65535.0 ; coord = scene_min + f*scene_extent
+// Device record i is built from source node order[i]; child indices are rewritten with
+// rank[] (rank[order[i]] = i).  The renumbering puts the nodes in breadth-first order from the
+// root, so the top levels of the tree are the first records; nothing outside the traversal ever
+// sees a node index, so results are unchanged.  Indices that point outside the buffer stay as
+// they are (they select the all-zero record either way).
 __global__ void repack_nodes_kernel(const uint32_t *__restrict__ src, uint32_t n, float3 smin, float3 sext,
+                                    const uint32_t *__restrict__ order, const uint32_t *__restrict__ rank,
                                     float4 *__restrict__ dst) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
     uint32_t w[16];
+    const uint32_t from = (i < n) ? order[i] : 0u;
 #pragma unroll
-    for (int k = 0; k < 16; k++) w[k] = (i < n) ? src[(size_t)i * 16 + k] : 0u;
+    for (int k = 0; k < 16; k++) w[k] = (i < n) ? src[(size_t)from * 16 + k] : 0u;
+#pragma unroll
+    for (int k = 12; k < 16; k++) {
+        const uint32_t idx = w[k] & 0x3FFFFFFFu;
+        if ((w[k] >> 30) == 3u && idx < n) w[k] = 0xC0000000u | rank[idx];
+    }
 #if RT_NODE64
     uint4 *o = reinterpret_cast<uint4 *>(dst) + (size_t)i * 4;
 #pragma unroll
@@ -304,10 +319,10 @@ __global__ void repack_mats_kernel(const uint32_t *__restrict__ src, uint32_t n,
 
 static inline unsigned grid_for(uint32_t n_plus_sentinel) { return (n_plus_sentinel + 255u) / 256u; }
 
-void launch_repack_nodes(const uint32_t *src, uint32_t n, const float smin[3], const float sext[3], float4 *dst,
-                         hipStream_t s) {
+void launch_repack_nodes(const uint32_t *src, uint32_t n, const float smin[3], const float sext[3],
+                         const uint32_t *order, const uint32_t *rank, float4 *dst, hipStream_t s) {
     hipLaunchKernelGGL(repack_nodes_kernel, dim3(grid_for(n + 1)), dim3(256), 0, s, src, n,
-                       make_float3(smin[0], smin[1], smin[2]), make_float3(sext[0], sext[1], sext[2]), dst);
+                       make_float3(smin[0], smin[1], smin[2]), make_float3(sext[0], sext[1], sext[2]), order, rank, dst);
 }
 void launch_repack_tris(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s) {
     hipLaunchKernelGGL(repack_tris_kernel, dim3(grid_for(n + 1)), dim3(256), 0, s, src, n, dst);
@@ -428,7 +443,16 @@ __device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeR
     nd.ax = np[0], nd.ay = np[1], nd.az = np[2], nd.mw = np[3];
 #else
     const float4 *np = sc.nodes + (size_t)ni * kNodeVec;
+#if RT_EXPERIMENT_SPLIT_LOADS  // timing experiment: same bytes, twice the load instructions
+    const float2 *hp = reinterpret_cast<const float2 *>(np);
+    const float2 *hq = hp + 1;
+    asm volatile("" : "+v"(hq));  // hides that hq = hp + 1, so the halves are not merged back
+#define LD2(k) make_float4(hp[2 * (k)].x, hp[2 * (k)].y, hq[2 * (k)].x, hq[2 * (k)].y)
+    nd.lox = LD2(0), nd.hix = LD2(1), nd.loy = LD2(2), nd.hiy = LD2(3), nd.loz = LD2(4), nd.hiz = LD2(5), nd.mt = LD2(6);
+#undef LD2
+#else
     nd.lox = np[0], nd.hix = np[1], nd.loy = np[2], nd.hiy = np[3], nd.loz = np[4], nd.hiz = np[5], nd.mt = np[6];
+#endif
 #endif
 }
 
@@ -975,6 +999,7 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
     uint32_t *stack = lds_stack + threadIdx.x;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0;
+    uint32_t warm_sink = 0u;  // keeps the cache-warming loads alive; word 28 of a node record is padding, always zero
     if (live) {
         Path ps;
         primary_ray(sc, p.W, p.H, x, y, p.time, ps);
@@ -1019,8 +1044,25 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
                 LeafList ll;
                 node_test<STATS, RT_TRACE_BLOCK, RT_STACK_LDS, true>(sc, nd, ps.O, ID, best, sp, stack, spill, ll, st, &cur,
                                                                &have);
+#if RT_WARM
+                // Nothing touches the stack until the next visit, so the pop can be done now; one
+                // dword of the next node is then requested before the pending leaves are
+                // intersected.  It costs one register, and the node's cache line is on its way
+                // (or in L1) by the time the next visit loads it, instead of that latency being
+                // paid after the leaves'.
+                if (!have && sp > 0) {
+                    cur = stack_pop<RT_TRACE_BLOCK, RT_STACK_LDS>(sp, stack, spill);
+                    have = true;
+                }
+                uint32_t warm = 0u;
+                if (have) warm = reinterpret_cast<const uint32_t *>(sc.nodes + (size_t)min(cur, sc.n_nodes) * kNodeVec)[28];
+                while (ll.n > 0) leaf_one<STATS>(sc, ps.O, ps.D, best, code, ll, st);
+                warm_sink ^= warm;
+                if (!have) break;
+#else
                 while (ll.n > 0) leaf_one<STATS>(sc, ps.O, ps.D, best, code, ll, st);
                 if (!have && sp == 0) break;
+#endif
             }
 #else
             while (sp > 0) node_step<STATS, RT_TRACE_BLOCK, RT_STACK_LDS>(sc, ps.O, ps.D, ID, best, code, sp, stack, spill, st);
@@ -1043,7 +1085,7 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
             write_aux_tail(p.aux, pix, ps, nrays);
         }
     }
-    flush_counters<STATS>(p.counters, lane, nrays, st);
+    flush_counters<STATS>(p.counters, lane, nrays + warm_sink, st);
 }
 
 void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s) {
