@@ -14,16 +14,23 @@
 namespace rt {
 
 #define RT_BLOCK 256
-#define RT_TRACE_BLOCK 64  // megakernel workgroup: one wavefront (an 8x8 quarter of a 16x16 tile)
+#ifndef RT_LDS_TOP
+#define RT_LDS_TOP 85      // megakernel: number of leading (breadth-first) nodes kept in LDS per workgroup (85 = four levels); 0 = none
+#endif
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 4   // megakernel: wavefronts per workgroup (each an 8x8 quarter of a 16x16 tile); 1, 2, 4 or 8
+#endif
+#define RT_TRACE_BLOCK (64 * RT_TRACE_WAVES)
+#define RT_TOP_STRIDE 9    // float4 per cached node: 144 B, so that 16 lanes on 16 different nodes use 16 different bank groups
 // Traversal stack: the first RT_STACK_LDS entries of every lane live in LDS (lane-contiguous, so
 // conflict-free); deeper entries spill to per-lane private memory.  The reference's own array
 // has 32 entries and no overflow guard; here pushes beyond RT_STACK_LDS + RT_STACK_SPILL are
 // dropped and counted.
 #ifndef RT_STACK_LDS
-#define RT_STACK_LDS 20
+#define RT_STACK_LDS 8
 #endif
 #ifndef RT_STACK_SPILL
-#define RT_STACK_SPILL 44
+#define RT_STACK_SPILL 56
 #endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 8  // megakernel: waves per SIMD the register allocator must leave room for
@@ -435,24 +442,23 @@ struct NodeRegs {
 #endif
 };
 
-// Issues the loads of node ni.
-__device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeRegs &nd) {
+// Issues the loads of node ni.  TOP > 0: the first TOP nodes (breadth-first numbering, i.e. the top
+// levels of the tree) are read from the workgroup's LDS copy `top` instead of through the vector
+// memory pipeline, which is what bounds this kernel.
+template <int TOP = 0>
+__device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeRegs &nd, const float4 *top = nullptr) {
     ni = min(ni, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
 #if RT_NODE64
     const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes) + (size_t)ni * 4;
     nd.ax = np[0], nd.ay = np[1], nd.az = np[2], nd.mw = np[3];
 #else
+    if (TOP > 0 && ni < (uint32_t)TOP) {
+        const float4 *tp = top + ni * RT_TOP_STRIDE;
+        nd.lox = tp[0], nd.hix = tp[1], nd.loy = tp[2], nd.hiy = tp[3], nd.loz = tp[4], nd.hiz = tp[5], nd.mt = tp[6];
+        return;
+    }
     const float4 *np = sc.nodes + (size_t)ni * kNodeVec;
-#if RT_EXPERIMENT_SPLIT_LOADS  // timing experiment: same bytes, twice the load instructions
-    const float2 *hp = reinterpret_cast<const float2 *>(np);
-    const float2 *hq = hp + 1;
-    asm volatile("" : "+v"(hq));  // hides that hq = hp + 1, so the halves are not merged back
-#define LD2(k) make_float4(hp[2 * (k)].x, hp[2 * (k)].y, hq[2 * (k)].x, hq[2 * (k)].y)
-    nd.lox = LD2(0), nd.hix = LD2(1), nd.loy = LD2(2), nd.hiy = LD2(3), nd.loz = LD2(4), nd.hiz = LD2(5), nd.mt = LD2(6);
-#undef LD2
-#else
     nd.lox = np[0], nd.hix = np[1], nd.loy = np[2], nd.hiy = np[3], nd.loz = np[4], nd.hiz = np[5], nd.mt = np[6];
-#endif
 #endif
 }
 
@@ -469,14 +475,14 @@ __device__ __forceinline__ uint32_t stack_pop(int &sp, const uint32_t *stack, co
 }
 
 // Pops the next node index and issues its loads.
-template <bool STATS, int STRIDE, int LDS_DEPTH>
+template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP = 0>
 __device__ __forceinline__ void node_fetch(const DevScene &sc, int &sp, const uint32_t *stack, const uint32_t *spill,
-                                           NodeRegs &nd, LaneStats &st) {
+                                           NodeRegs &nd, LaneStats &st, const float4 *top = nullptr) {
     if (STATS) {
         st.max_sp = max(st.max_sp, (uint32_t)sp);
         st.nodes++;
     }
-    node_load(sc, stack_pop<STRIDE, LDS_DEPTH>(sp, stack, spill), nd);
+    node_load<TOP>(sc, stack_pop<STRIDE, LDS_DEPTH>(sp, stack, spill), nd, top);
 }
 
 // Slab tests, sort, pushes and leaf list for a fetched node.
@@ -593,11 +599,11 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
     ll.n = nl;
 }
 
-template <bool STATS, int STRIDE, int LDS_DEPTH>
+template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP = 0>
 __device__ __forceinline__ void node_part(const DevScene &sc, v3 O, v3 ID, float best, int &sp, uint32_t *stack,
-                                          uint32_t *spill, LeafList &ll, LaneStats &st) {
+                                          uint32_t *spill, LeafList &ll, LaneStats &st, const float4 *top = nullptr) {
     NodeRegs nd;
-    node_fetch<STATS, STRIDE, LDS_DEPTH>(sc, sp, stack, spill, nd, st);
+    node_fetch<STATS, STRIDE, LDS_DEPTH, TOP>(sc, sp, stack, spill, nd, st, top);
     node_test<STATS, STRIDE, LDS_DEPTH>(sc, nd, O, ID, best, sp, stack, spill, ll, st);
 }
 
@@ -634,11 +640,12 @@ __device__ __forceinline__ void leaf_one(const DevScene &sc, v3 O, v3 D, float &
 }
 
 // One iteration of the reference's `while (stackPtr > 0)` loop.
-template <bool STATS, int STRIDE, int LDS_DEPTH>
+template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP = 0>
 __device__ __forceinline__ void node_step(const DevScene &sc, v3 O, v3 D, v3 ID, float &best, uint32_t &best_code,
-                                          int &sp, uint32_t *stack, uint32_t *spill, LaneStats &st) {
+                                          int &sp, uint32_t *stack, uint32_t *spill, LaneStats &st,
+                                          const float4 *top = nullptr) {
     LeafList ll;
-    node_part<STATS, STRIDE, LDS_DEPTH>(sc, O, ID, best, sp, stack, spill, ll, st);
+    node_part<STATS, STRIDE, LDS_DEPTH, TOP>(sc, O, ID, best, sp, stack, spill, ll, st, top);
 #if RT_LANE_PROFILE
     if (STATS && first_active_lane()) st.box++;
     while (ll.n > 0) {
@@ -925,7 +932,7 @@ __device__ __forceinline__ bool tile_pixel(const TraceParams &p, bool sharded, i
     return live;
 }
 
-// Pixel of a megakernel lane (one-wavefront workgroups, 8x8 pixels each, four per 16x16 tile).
+// Pixel of a megakernel lane (wavefronts of 8x8 pixels, four per 16x16 tile, RT_TRACE_WAVES per workgroup).
 // Consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2, so b & 7 names
 // the XCD and b >> 3 counts within it.  Macro tiles (RT_MACRO x RT_MACRO tiles) are dealt to the
 // XCDs in turn: an XCD works on compact screen regions (its rays share nodes in its L2) while
@@ -934,8 +941,10 @@ __device__ __forceinline__ bool trace_pixel(const TraceParams &p, bool sharded, 
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u;
     uint32_t tx, ty, wave;
 #if RT_XCD_MAP == 2
+    static_assert((RT_MACRO * RT_MACRO * 4) % RT_TRACE_WAVES == 0, "a workgroup must not straddle macro tiles");
     const uint32_t mxn = (p.tiles_x + RT_MACRO - 1) / RT_MACRO, myn = (p.tiles_y + RT_MACRO - 1) / RT_MACRO;
-    const uint32_t j = b >> 3, per_macro = RT_MACRO * RT_MACRO * 4u;
+    // j: index of this wavefront among those of its XCD
+    const uint32_t j = (b >> 3) * RT_TRACE_WAVES + (threadIdx.x >> 6), per_macro = RT_MACRO * RT_MACRO * 4u;
     const uint32_t macro = (j / per_macro) * 8u + (b & 7u), r = j % per_macro;
     if (macro >= mxn * myn) return false;
     const uint32_t t = r >> 2;
@@ -944,12 +953,14 @@ __device__ __forceinline__ bool trace_pixel(const TraceParams &p, bool sharded, 
     ty = (macro / mxn) * RT_MACRO + (t / RT_MACRO);
     if (tx >= p.tiles_x || ty >= p.tiles_y) return false;
 #elif RT_XCD_MAP == 1
+    static_assert(RT_TRACE_WAVES == 1, "mapping 1 is written for one-wavefront workgroups");
     const uint32_t per = (p.ntiles + 7u) / 8u, j = b >> 3;
     const uint32_t tile = (b & 7u) * per + (j >> 2);
     if (tile >= p.ntiles) return false;
     wave = j & 3u;
     tx = tile % p.tiles_x, ty = tile / p.tiles_x;
 #else
+    static_assert(RT_TRACE_WAVES == 1, "mapping 0 is written for one-wavefront workgroups");
     const uint32_t tile = b >> 2;
     if (tile >= p.ntiles) return false;
     wave = b & 3u;
@@ -993,6 +1004,18 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_TRACE_BLOCK];
     uint32_t spill[RT_STACK_SPILL];
     const DevScene &sc = p.scene;
+#if RT_LDS_TOP > 0
+    // the workgroup's copy of the top of the tree (breadth-first numbering: the first records)
+    __shared__ float4 lds_top[RT_LDS_TOP * RT_TOP_STRIDE];
+    for (uint32_t k = threadIdx.x; k < RT_LDS_TOP * 7u; k += RT_TRACE_BLOCK) {
+        const uint32_t node = k / 7u, part = k % 7u;
+        lds_top[node * RT_TOP_STRIDE + part] = sc.nodes[(size_t)min(node, sc.n_nodes) * kNodeVec + part];
+    }
+    __syncthreads();
+    const float4 *top = lds_top;
+#else
+    const float4 *top = nullptr;
+#endif
     int x, y;
     bool live = trace_pixel(p, MODE == 1, x, y);
     uint32_t lane = threadIdx.x & 63u;
@@ -1065,7 +1088,8 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
 #endif
             }
 #else
-            while (sp > 0) node_step<STATS, RT_TRACE_BLOCK, RT_STACK_LDS>(sc, ps.O, ps.D, ID, best, code, sp, stack, spill, st);
+            while (sp > 0)
+                node_step<STATS, RT_TRACE_BLOCK, RT_STACK_LDS, RT_LDS_TOP>(sc, ps.O, ps.D, ID, best, code, sp, stack, spill, st, top);
 #endif
             nrays++;
             bool exists;
@@ -1093,7 +1117,7 @@ void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStrea
     // 8 equal runs of workgroups, one per XCD; surplus workgroups exit at once
 #if RT_XCD_MAP == 2
     const uint32_t mx = (p.tiles_x + RT_MACRO - 1) / RT_MACRO, my = (p.tiles_y + RT_MACRO - 1) / RT_MACRO;
-    const uint32_t groups = ((mx * my + 7u) / 8u) * 8u * (RT_MACRO * RT_MACRO * 4u);
+    const uint32_t groups = ((mx * my + 7u) / 8u) * 8u * (RT_MACRO * RT_MACRO * 4u) / RT_TRACE_WAVES;
 #elif RT_XCD_MAP == 1
     const uint32_t groups = ((p.ntiles + 7u) / 8u) * 8u * 4u;
 #else
