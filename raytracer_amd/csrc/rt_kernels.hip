@@ -21,7 +21,9 @@ namespace rt {
 #define RT_TRACE_WAVES 4   // megakernel: wavefronts per workgroup (each an 8x8 quarter of a 16x16 tile); 1, 2, 4 or 8
 #endif
 #define RT_TRACE_BLOCK (64 * RT_TRACE_WAVES)
+#ifndef RT_TOP_STRIDE
 #define RT_TOP_STRIDE 9    // float4 per cached node: 144 B, so that 16 lanes on 16 different nodes use 16 different bank groups
+#endif
 // Traversal stack: the first RT_STACK_LDS entries of every lane live in LDS (lane-contiguous, so
 // conflict-free); deeper entries spill to per-lane private memory.  The reference's own array
 // has 32 entries and no overflow guard; here pushes beyond RT_STACK_LDS + RT_STACK_SPILL are
