@@ -4,7 +4,7 @@
 Traces every ray of one frame of the bench workload with the CPU restatement (node visits and
 leaf intersections per visit), then replays 64-lane wavefronts under different policies and
 reports wavefront-instructions per ray with a simple cost model (one node step, one leaf step,
-one shading step).  Test/analysis tooling only.
+one shading step).  TEST INFRASTRUCTURE (part of oracle/): analysis tooling only, never on the product path.
 """
 import argparse
 import ctypes as C
@@ -13,7 +13,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "oracle"))
 import bench  # noqa: E402

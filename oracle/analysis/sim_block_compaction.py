@@ -1,6 +1,6 @@
-"""Offline scheduling study on traced rays (see sched_sim.py): analysis tooling only."""
+"""TEST INFRASTRUCTURE (part of oracle/): offline scheduling study on traced rays (see sched_sim.py)."""
 import sys, numpy as np
-import os; sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import sched_sim as SS
 class A: width=1920; height=1080; bounces=4; detail=1.0; obj=None
 tr = SS.trace_frame(A)
