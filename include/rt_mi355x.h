@@ -53,8 +53,10 @@ typedef struct {
     uint64_t max_stack;     /* deepest traversal stack seen (RT_FLAG_STATS only)                 */
     uint64_t stack_overflows; /* pushes dropped because the stack was full (always counted)      */
     uint64_t hits;          /* rays that hit a surface (RT_FLAG_STATS only)                      */
-    double last_render_ms;  /* device time of the last rt_render / rt_render_sum call            */
-    double last_trace_ms;   /* device time spent in the trace kernel(s) of that call             */
+    double last_render_ms;  /* last rt_render / rt_render_sum call: device time from its first to its
+                               last piece of work, every stream included (valid after rt_sync)   */
+    double last_trace_ms;   /* sum of the durations of that call's trace launches (first 256);
+                               launches of one call overlap, so this can exceed last_render_ms    */
 } rt_stats;
 
 /* Stands in for Renderer.__init__ (src/renderer/renderer.py:64-154): creates the device
@@ -65,7 +67,10 @@ int rt_destroy(rt_ctx *ctx);
 /* Message for the most recent failure on the calling thread. */
 const char *rt_last_error(void);
 
-/* Renderer.update_size (renderer.py:347-382): reallocates the three images, contents zeroed. */
+/* Renderer.update_size (renderer.py:347-382): reallocates the three images, contents zeroed.
+ * Deviation: the accumulated-frame count returns to 0 here, whereas the reference's update_size
+ * leaves `rendered_frames` alone (its next frame is blended into the fresh, black texture with
+ * weight 1/(N+1)).  A caller that keeps its own counter must reset it after a resize. */
 int rt_resize(rt_ctx *ctx, int width, int height);
 
 /* Renderer.update_ssbo (renderer.py:308-324): copies `nbytes` of host data into the buffer

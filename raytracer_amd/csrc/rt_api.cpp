@@ -86,6 +86,8 @@ struct rt_ctx {
     hipEvent_t ev_ready = nullptr;                // `stream` work the trace streams must observe
     hipEvent_t ev_tdone[2] = {nullptr, nullptr};  // last trace kernel of a trace stream
     hipEvent_t ev_acc[2] = {nullptr, nullptr};    // last accumulate pass that read sample image b
+    hipEvent_t ev_tlast[2] = {nullptr, nullptr};  // timed: end of the last call's last launch on trace stream b
+    bool tlast_used[2] = {false, false};
     bool main_dirty = true;                       // something was queued on `stream` since ev_ready
     bool need_ready[2] = {false, false};
     bool acc_recorded[2] = {false, false};
@@ -147,28 +149,41 @@ int vecs_per_elem(int binding) {
     }
 }
 
-int alloc_images(rt_ctx *c) {
-    size_t n = (size_t)c->W * c->H;
-    for (float4 **p : {&c->sample, &c->sample2, &c->acc, &c->sum, &c->sum2}) {
-        if (*p) HIP_TRY(hipFree(*p));
-        *p = nullptr;
-        HIP_TRY(hipMalloc((void **)p, n * sizeof(float4)));
-        HIP_TRY(hipMemsetAsync(*p, 0, n * sizeof(float4), c->stream));
+// (Re)allocates the images and the ray queue for width x height.  Everything new is allocated
+// before anything old is released: on failure the context keeps its previous size and images.
+int alloc_images(rt_ctx *c, int width, int height) {
+    const size_t n = (size_t)width * height;
+    // ray queue of the wavefront pipeline: one slot per lane of the 16x16 tile grid
+    const size_t tiles = (size_t)((width / 8 * 8 + 15) / 16) * (size_t)((height / 4 * 4 + 15) / 16);
+    const size_t slots = ((tiles + 7) / 8) * 8 * 256 + 256;
+    void **dst[8] = {(void **)&c->sample, (void **)&c->sample2, (void **)&c->acc,      (void **)&c->sum,
+                     (void **)&c->sum2,   (void **)&c->q.rays[0], (void **)&c->q.hits, (void **)&c->q.paths};
+    const size_t bytes[8] = {n * sizeof(float4), n * sizeof(float4), n * sizeof(float4), n * sizeof(float4),
+                             n * sizeof(float4), slots * 2 * sizeof(float4), slots * sizeof(float2),
+                             slots * 2 * sizeof(float4)};
+    void *fresh[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 8; i++) {
+        hipError_t e = hipMalloc(&fresh[i], bytes[i]);
+        if (e == hipSuccess && i < 5) e = hipMemsetAsync(fresh[i], 0, bytes[i], c->stream);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(c->stream);
+            for (int k = 0; k <= i; k++)
+                if (fresh[k]) (void)hipFree(fresh[k]);
+            (void)hipGetLastError();  // the failure is reported here, not by a later call
+            return fail(std::string("allocating a ") + std::to_string(width) + "x" + std::to_string(height) +
+                        " image set: " + hipGetErrorString(e));
+        }
+    }
+    for (int i = 0; i < 8; i++) {
+        if (*dst[i]) (void)hipFree(*dst[i]);
+        *dst[i] = fresh[i];
     }
     if (c->aux) {
-        HIP_TRY(hipFree(c->aux));
+        (void)hipFree(c->aux);
         c->aux = nullptr;
     }
-    // ray queue of the wavefront pipeline: one slot per lane of the 16x16 tile grid
-    for (void **p : {(void **)&c->q.rays[0], (void **)&c->q.hits, (void **)&c->q.paths}) {
-        if (*p) HIP_TRY(hipFree(*p));
-        *p = nullptr;
-    }
-    size_t tiles = (size_t)((c->W / 8 * 8 + 15) / 16) * (size_t)((c->H / 4 * 4 + 15) / 16);
-    size_t slots = ((tiles + 7) / 8) * 8 * 256 + 256;
-    HIP_TRY(hipMalloc((void **)&c->q.rays[0], slots * 2 * sizeof(float4)));
-    HIP_TRY(hipMalloc((void **)&c->q.hits, slots * sizeof(float2)));
-    HIP_TRY(hipMalloc((void **)&c->q.paths, slots * 2 * sizeof(float4)));
+    c->W = width;
+    c->H = height;
     c->rendered_frames = 0;
     c->main_dirty = true;
     c->sum2_dirty = false;
@@ -342,6 +357,7 @@ uint64_t owned_pixels(int WW, int HH, uint32_t shard, uint32_t nshards) {
 int begin_timed(rt_ctx *c) {
     HIP_TRY(hipEventRecord(c->ev_begin, c->stream));
     c->ev_trace_used = 0;
+    c->tlast_used[0] = c->tlast_used[1] = false;
     return 0;
 }
 
@@ -368,13 +384,7 @@ extern "C" {
 
 const char *rt_last_error(void) { return g_err.c_str(); }
 
-int rt_create(int device, rt_ctx **out) {
-    if (!out) return fail("rt_create: out is null");
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail("rt_create: no such HIP device");
-    HIP_TRY(hipSetDevice(device));
-    rt_ctx *c = new rt_ctx();
+static int create_impl(rt_ctx *c, int device) {
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev_begin));
@@ -384,6 +394,7 @@ int rt_create(int device, rt_ctx **out) {
         HIP_TRY(hipStreamCreateWithFlags(&c->tstream[b], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_tdone[b], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_acc[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreate(&c->ev_tlast[b]));
     }
     if (const char *e = getenv("RT_OVERLAP")) c->overlap = atoi(e) != 0;
     HIP_TRY(hipMalloc((void **)&c->counters, sizeof(rt::Counters) * rt::kCounterStripes));
@@ -402,34 +413,50 @@ int rt_create(int device, rt_ctx **out) {
     if (c->refill_threshold < 1u) c->refill_threshold = 1u;
     if (c->refill_threshold > 64u) c->refill_threshold = 64u;
     if (c->extend_waves < 1u) c->extend_waves = 1u;
-    if (int rc = alloc_images(c)) return rc;
+    return alloc_images(c, c->W, c->H);
+}
+
+int rt_create(int device, rt_ctx **out) {
+    if (!out) return fail("rt_create: out is null");
+    *out = nullptr;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail("rt_create: no such HIP device: " + std::to_string(device) + " (" + std::to_string(ndev) +
+                    " visible)");
+    HIP_TRY(hipSetDevice(device));
+    rt_ctx *c = new rt_ctx();
+    if (int rc = create_impl(c, device)) {
+        const std::string why = g_err;  // rt_destroy releases whatever was created so far
+        rt_destroy(c);
+        g_err = why;
+        return rc;
+    }
     *out = c;
     return 0;
 }
 
+// Tolerates a partially constructed context (null streams, events and buffers).
 int rt_destroy(rt_ctx *c) {
     if (!c) return 0;
-    hipSetDevice(c->device);
-    for (int b = 0; b < 2; b++) hipStreamSynchronize(c->tstream[b]);
-    hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    for (int b = 0; b < 2; b++)
+        if (c->tstream[b]) (void)hipStreamSynchronize(c->tstream[b]);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (RawBuffer *b : {&c->spheres, &c->planes, &c->boxes, &c->mats, &c->nodes, &c->tris}) {
-        if (b->raw) hipFree(b->raw);
-        if (b->packed) hipFree(b->packed);
+        if (b->raw) (void)hipFree(b->raw);
+        if (b->packed) (void)hipFree(b->packed);
     }
-    for (void *p : {(void *)c->node_order, (void *)c->node_rank, (void *)c->sample, (void *)c->sample2, (void *)c->acc, (void *)c->sum, (void *)c->sum2,
-                    (void *)c->aux, (void *)c->counters,
-                    (void *)c->q.rays[0], (void *)c->q.hits, (void *)c->q.paths})
-        if (p) hipFree(p);
-    for (hipEvent_t e : c->ev_trace) hipEventDestroy(e);
-    hipEventDestroy(c->ev_begin);
-    hipEventDestroy(c->ev_end);
-    hipEventDestroy(c->ev_ready);
-    for (int b = 0; b < 2; b++) {
-        hipEventDestroy(c->ev_tdone[b]);
-        hipEventDestroy(c->ev_acc[b]);
-        hipStreamDestroy(c->tstream[b]);
-    }
-    hipStreamDestroy(c->stream);
+    for (void *p : {(void *)c->node_order, (void *)c->node_rank, (void *)c->sample, (void *)c->sample2, (void *)c->acc,
+                    (void *)c->sum, (void *)c->sum2, (void *)c->aux, (void *)c->counters, (void *)c->q.rays[0],
+                    (void *)c->q.hits, (void *)c->q.paths})
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->ev_trace) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {c->ev_begin, c->ev_end, c->ev_ready, c->ev_tdone[0], c->ev_tdone[1], c->ev_acc[0], c->ev_acc[1],
+                         c->ev_tlast[0], c->ev_tlast[1]})
+        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : {c->tstream[0], c->tstream[1], c->stream})
+        if (st) (void)hipStreamDestroy(st);
     delete c;
     return 0;
 }
@@ -440,9 +467,7 @@ int rt_resize(rt_ctx *c, int width, int height) {
     if ((size_t)width * (size_t)height > ((size_t)1 << 28)) return fail("rt_resize: image too large");
     HIP_TRY(hipSetDevice(c->device));
     if (int rc = sync_all(c)) return rc;
-    c->W = width;
-    c->H = height;
-    return alloc_images(c);
+    return alloc_images(c, width, height);
 }
 
 int rt_upload(rt_ctx *c, int binding, const void *data, size_t nbytes) {
@@ -599,6 +624,13 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
         out->last_render_ms = ms;
+        // overlapped sum-mode launches run on the trace streams, which `stream` (where ev_end was
+        // recorded) had not joined yet: the call ends when the last of them does
+        for (int b = 0; b < 2; b++)
+            if (c->tlast_used[b]) {
+                HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin, c->ev_tlast[b]));
+                if (ms > out->last_render_ms) out->last_render_ms = ms;
+            }
         double t = 0.0;
         for (size_t i = 0; i + 1 < c->ev_trace_used; i += 2) {
             HIP_TRY(hipEventElapsedTime(&ms, c->ev_trace[i], c->ev_trace[i + 1]));
@@ -652,6 +684,8 @@ int rt_render_sum(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounc
         c->pixel_samples += owned;
         if (int rc = trace_event(c, ts)) return rc;
         if (ts != c->stream) {
+            HIP_TRY(hipEventRecord(c->ev_tlast[b], ts));
+            c->tlast_used[b] = true;
             c->tpending[b] = true;
             if (b) {
                 c->sum2_dirty = true;
@@ -689,6 +723,7 @@ int rt_finalize_sum(rt_ctx *c, const float *sum_rgba, uint32_t spp) {
     rt::launch_finalize_sum(sum_rgba ? reinterpret_cast<const float4 *>(sum_rgba) : c->sum, c->acc,
                             (size_t)c->W * c->H, spp, c->stream);
     HIP_TRY(hipGetLastError());
+    c->main_dirty = true;  // a later overlapped frame adds into the image this pass reads
     return 0;
 }
 

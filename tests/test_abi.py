@@ -41,3 +41,22 @@ def test_renderer_argument_checks_do_not_need_a_gpu():
         is_positive_int(-1)
     with pytest.raises(TypeError):
         is_positive_int("4")
+
+
+def test_rt_create_failure_reports_and_leaves_nothing_behind():
+    """A failing rt_create returns non-zero, describes the failure and hands back no context (it
+    frees whatever it had created); rt_destroy(NULL) is a no-op.  Works with or without a GPU: without
+    one the device count query fails, with one device 9999 does not exist."""
+    from raytracer_amd import _lib
+
+    L = _lib.load()
+    for _ in range(3):
+        ctx = ctypes.c_void_p(0xDEAD)
+        assert L.rt_create(9999, ctypes.byref(ctx)) != 0
+        assert ctx.value is None
+        assert len(L.rt_last_error()) > 0
+    assert L.rt_create(0, None) != 0
+    assert b"out is null" in L.rt_last_error()
+    assert L.rt_destroy(None) == 0
+    assert L.rt_resize(None, 64, 64) != 0
+    assert b"null context" in L.rt_last_error()

@@ -405,6 +405,73 @@ def test_interactive_hooks_reset_the_running_mean(renderer):
         renderer.bounces = -1
 
 
+def test_finalize_then_more_frames_without_clear(renderer):
+    """Progressive preview: render_sum, finalize_sum, render_sum, ... with no clear in between.  The
+    finalize pass reads the sum image on the main stream while later frames add into it from the
+    trace streams; they must be ordered.  The sum after every step equals the per-frame expectation
+    bit for bit, and every preview equals the finalised image of that expectation."""
+    import ctypes as C
+
+    w, h, b = 320, 180, 4
+    load_golden_scene(renderer, "gally")
+    renderer.update_size(w, h)
+    renderer.bounces = b
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def read_sum():
+        renderer.sync()
+        p, n = renderer.sum_buffer()
+        host = np.empty((h, w, 4), np.float32)
+        assert hip.hipMemcpy(host.ctypes.data, C.c_void_p(p), n, 2) == 0
+        return host
+
+    per_frame = []
+    for f in range(5):
+        renderer.clear_sum()
+        renderer.render_sum(f, 1)
+        per_frame.append(read_sum())
+    # reference previews: finalize of a sum built in the same order, one clear + one finalize each
+    def preview_of(total):
+        renderer.clear_sum()
+        p, n = renderer.sum_buffer()
+        renderer.sync()
+        assert hip.hipMemcpy(C.c_void_p(p), total.ctypes.data, n, 1) == 0
+        renderer.finalize_sum(int(total[0, 0, 3]))
+        return renderer.read_accumulation()
+
+    for _ in range(3):  # repeated: an unordered read/write would show up only sometimes
+        renderer.clear_sum()
+        # frame k goes to the sum image itself when k is even, to the second image (folded in by
+        # the next finalize) when k is odd; a finalize after every frame makes the order running
+        total = np.zeros_like(per_frame[0])
+        previews = []
+        for f in range(5):
+            renderer.render_sum(f, 1)
+            total = total + per_frame[f]
+            renderer.finalize_sum(f + 1)       # no sync, no clear
+            if f in (1, 4):
+                previews.append((f, renderer.read_accumulation(), total.copy()))
+        got = read_sum()
+        assert np.array_equal(got.view(np.uint32), total.view(np.uint32))
+        for f, img, tot in previews:
+            assert np.array_equal(img.view(np.uint32), preview_of(tot).view(np.uint32)), f"preview after frame {f}"
+
+
+def test_failed_resize_keeps_the_context_usable(renderer):
+    """rt_resize refuses an absurd size with a message and leaves the previous images in place."""
+    load_golden_scene(renderer, "debug")
+    sc = O.OracleScene.from_dir(GOLDEN / "debug")
+    img = render_frame(renderer, 64, 32, 0, 2)
+    L, ctx = renderer._L, renderer._ctx
+    assert L.rt_resize(ctx, 1 << 20, 1 << 20) != 0
+    assert b"too large" in L.rt_last_error()
+    assert L.rt_resize(ctx, 0, 5) != 0
+    assert np.array_equal(renderer.read_sample(), img)          # same size, same contents
+    img2 = render_frame(renderer, 64, 32, 1, 2)
+    assert np.array_equal(img2.view(np.uint32), sc.render(64, 32, 1, 2).view(np.uint32))
+
+
 def test_error_reporting(renderer):
     with pytest.raises(ValueError):
         renderer.update_ssbo(0, np.zeros(64, np.uint8), 13)
