@@ -141,6 +141,41 @@ int rt_clear_sum(rt_ctx *ctx, float *sum_rgba);
 /* accumulation image = srgb(sum / spp), alpha 1 */
 int rt_finalize_sum(rt_ctx *ctx, const float *sum_rgba, uint32_t spp);
 
+/*
+ * One frame without any allocation.  No counterpart in the reference; it is for callers that
+ * cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  A variant of rt_render (same kernels, same results bit for bit) that takes no
+ * context: every input is a DEVICE pointer to a buffer in the reference's layout (the bindings
+ * above), the outputs are caller-owned device images of width*height RGBA32F, and the work is
+ * queued on `stream` (a hipStream_t, NULL = the default stream) without waiting for it.
+ * `sample_rgba` receives what the compute pass stores for time = frame (pixels outside the
+ * dispatch's 8x4 groups are left untouched); if `acc_rgba` is not NULL the accumulate pass then
+ * folds the sample into it with weight 1/(accumulated_frames+1), as rt_render does.
+ * The device records the kernels read (what rt_upload + rt_render keep in hipMalloc'ed buffers) and
+ * the ray counters live in a fixed array inside the library, about 8.7 MB per GPU, held until the
+ * process ends; scenes beyond the RT_NOALLOC_MAX_* element counts are rejected with an error.
+ * Calls on one GPU share that array: calls that overlap in time on the same GPU race; calls
+ * queued on one stream (or ordered by events) do not.  Calls no hipMalloc / hipFree.
+ */
+#define RT_NOALLOC_MAX_NODES 32768u
+#define RT_NOALLOC_MAX_TRIANGLES 65536u
+#define RT_NOALLOC_MAX_SPHERES 4096u
+#define RT_NOALLOC_MAX_BOXES 4096u
+#define RT_NOALLOC_MAX_PLANES 256u
+#define RT_NOALLOC_MAX_MATERIALS 4096u
+typedef struct {
+    const void *spheres;   uint32_t n_spheres;    /* binding 5,  32 B/elem */
+    const void *planes;    uint32_t n_planes;     /* binding 6,  32 B/elem */
+    const void *boxes;     uint32_t n_boxes;      /* binding 7,  32 B/elem */
+    const void *materials; uint32_t n_materials;  /* binding 9,  12 B/elem */
+    const void *bvh;       uint32_t n_nodes;      /* binding 11, 64 B/elem */
+    const void *triangles; uint32_t n_triangles;  /* binding 12, 64 B/elem */
+    float scene_min[3], scene_extent[3];          /* host values of the uniforms */
+    float inv_view_proj[16], eye[3];
+} rt_scene_view;
+int rt_render_noalloc(int device, const rt_scene_view *scene, int width, int height, uint32_t frame, float bounces,
+                      float *sample_rgba, float *acc_rgba, uint32_t accumulated_frames, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ SYMBOLS = (
     "rt_create", "rt_destroy", "rt_last_error", "rt_resize", "rt_upload", "rt_set_scene_bounds", "rt_set_camera",
     "rt_render", "rt_reset_accumulation", "rt_rendered_frames", "rt_read_sample", "rt_read_accumulation",
     "rt_read_aux", "rt_get_stats", "rt_reset_stats", "rt_sync", "rt_render_sum", "rt_sum_buffer", "rt_clear_sum",
-    "rt_finalize_sum",
+    "rt_finalize_sum", "rt_render_noalloc",
 )
 
 RT_FLAG_AUX = 1
@@ -31,6 +31,18 @@ class RtStats(C.Structure):
                                            "max_stack", "stack_overflows", "hits")] + [("last_render_ms", C.c_double),
                                                                                ("last_trace_ms", C.c_double)]
 
+
+class RtSceneView(C.Structure):
+    """rt_scene_view: device pointers to reference-layout buffers plus the host uniform values."""
+    _fields_ = [("spheres", C.c_void_p), ("n_spheres", C.c_uint32), ("planes", C.c_void_p), ("n_planes", C.c_uint32),
+                ("boxes", C.c_void_p), ("n_boxes", C.c_uint32), ("materials", C.c_void_p), ("n_materials", C.c_uint32),
+                ("bvh", C.c_void_p), ("n_nodes", C.c_uint32), ("triangles", C.c_void_p), ("n_triangles", C.c_uint32),
+                ("scene_min", C.c_float * 3), ("scene_extent", C.c_float * 3), ("inv_view_proj", C.c_float * 16),
+                ("eye", C.c_float * 3)]
+
+
+# capacity of rt_render_noalloc's fixed device array (RT_NOALLOC_MAX_* in the header)
+NOALLOC_MAX = {"nodes": 32768, "triangles": 65536, "spheres": 4096, "boxes": 4096, "planes": 256, "materials": 4096}
 
 _lib = None
 
@@ -68,6 +80,8 @@ def load():
         "rt_sum_buffer": [vp, C.POINTER(vp), C.POINTER(C.c_size_t)],
         "rt_clear_sum": [vp, vp],
         "rt_finalize_sum": [vp, vp, C.c_uint32],
+        "rt_render_noalloc": [C.c_int, C.POINTER(RtSceneView), C.c_int, C.c_int, C.c_uint32, C.c_float, vp, vp,
+                              C.c_uint32, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

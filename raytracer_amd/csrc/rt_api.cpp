@@ -65,6 +65,8 @@ void breadth_first_order(const uint32_t *nodes, uint32_t n, std::vector<uint32_t
 
 }  // namespace
 
+void rt::set_last_error(const std::string &message) { g_err = message; }
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -413,6 +415,7 @@ static int create_impl(rt_ctx *c, int device) {
     if (c->refill_threshold < 1u) c->refill_threshold = 1u;
     if (c->refill_threshold > 64u) c->refill_threshold = 64u;
     if (c->extend_waves < 1u) c->extend_waves = 1u;
+    HIP_TRY(rt::noalloc_prepare_device(device));
     return alloc_images(c, c->W, c->H);
 }
 

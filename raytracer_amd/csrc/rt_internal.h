@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 namespace rt {
 
 // ---- device-side record layouts (what the repack kernels produce) -------------------------
@@ -85,5 +87,11 @@ void launch_accumulate(const float4 *sample, float4 *acc, size_t npixels, float 
 // acc = srgb(sum / spp)
 void launch_fold_sum(float4 *target, float4 *part, size_t npixels, hipStream_t s);
 void launch_finalize_sum(const float4 *sum, float4 *acc, size_t npixels, uint32_t spp, hipStream_t s);
+
+// message rt_last_error() returns on the calling thread (rt_api.cpp)
+void set_last_error(const std::string &message);
+// rt_noalloc.hip: resolves the device address of the fixed scratch array of GPU `device` (which
+// must be current) so that a later rt_render_noalloc finds it ready
+hipError_t noalloc_prepare_device(int device);
 
 }  // namespace rt

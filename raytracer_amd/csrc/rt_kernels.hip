@@ -214,20 +214,21 @@ __device__ __forceinline__ float draw(uint32_t &s) {
 // rank[] (rank[order[i]] = i).  The renumbering puts the nodes in breadth-first order from the
 // root, so the top levels of the tree are the first records; nothing outside the traversal ever
 // sees a node index, so results are unchanged.  Indices that point outside the buffer stay as
-// they are (they select the all-zero record either way).
+// they are (they select the all-zero record either way).  order == rank == nullptr keeps the
+// source numbering.
 __global__ void repack_nodes_kernel(const uint32_t *__restrict__ src, uint32_t n, float3 smin, float3 sext,
                                     const uint32_t *__restrict__ order, const uint32_t *__restrict__ rank,
                                     float4 *__restrict__ dst) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
     uint32_t w[16];
-    const uint32_t from = (i < n) ? order[i] : 0u;
+    const uint32_t from = (i < n) ? (order ? order[i] : i) : 0u;
 #pragma unroll
     for (int k = 0; k < 16; k++) w[k] = (i < n) ? src[(size_t)from * 16 + k] : 0u;
 #pragma unroll
     for (int k = 12; k < 16; k++) {
         const uint32_t idx = w[k] & 0x3FFFFFFFu;
-        if ((w[k] >> 30) == 3u && idx < n) w[k] = 0xC0000000u | rank[idx];
+        if ((w[k] >> 30) == 3u && idx < n && rank) w[k] = 0xC0000000u | rank[idx];
     }
 #if RT_NODE64
     uint4 *o = reinterpret_cast<uint4 *>(dst) + (size_t)i * 4;
