@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
 """Benchmark of the render hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config c4|c5]
 
-Workload (BASELINE.json's metric, "Mrays/s + ms/frame, sponza_full 1080p 4-bounce"): the
+Default workload `c4` (the metric's: "Mrays/s + ms/frame, sponza_full 1080p 4-bounce"): the
 Sponza-scale scene at 1920x1080, 1 sample per pixel per frame, 4 bounces, reference default
 camera.  `models/sponza_full.obj` is not distributed with the reference, so the deterministic
 stand-in `sponza_synth` (about 265 k triangles, raytracer_amd/synth.py) is rendered unless
 --obj names a model; the JSON line says which.
 
-A step = one full frame per GPU.  With N GPUs (one process per GPU, launched by
-torch.distributed.run) rank r renders the frames f with f % N == r — samples-per-pixel sharding,
-scene replicated — into its own fp32 linear-radiance sum image, and the images are combined
-with one RCCL reduce inside the timed region; per-GPU work is fixed, so scaling is weak and
-`value` is the rays all ranks traced per second.
+c4, one GPU: a step is one reference frame -- the compute dispatch plus the accumulate pass
+(`rt_render`, what `Renderer.render()` does).  The same loop in linear-sum mode (`rt_render_sum`,
+what multi-GPU runs use) is timed too and reported under `sum_mode`.
+c4, N GPUs: one process per GPU; rank r renders the frames f with f % N == r (samples-per-pixel
+sharding, scene replicated) into its own fp32 linear-radiance sum image; the images are combined
+with one RCCL reduce inside the timed region.  Per-GPU work is fixed: weak scaling.
+
+`--config c5` (strong scaling): one 3840x2160 image of 256 samples per pixel, split over the
+ranks by image tiles AND by samples; a step is the whole image, timed from the first launch to
+rank 0's finalised image, the reduce included.
+
+With WORLD_SIZE unset and --gpus N > 1 this script starts the N rank processes itself (before it
+touches a GPU) and relays rank 0's JSON line; under `python -m torch.distributed.run` it uses the
+ranks it is given.  Either way the collectives are RCCL called through the C ABI; no torch.
 """
 
 from __future__ import annotations
@@ -31,6 +40,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+PMC_FILE = ROOT / "profiles" / "pmc_trace_kernel.json"  # counters of the dominant kernel (separate rocprofv3 passes)
 
 
 def build_workload(args):
@@ -48,84 +58,96 @@ def build_workload(args):
     return name, bufs, time.time() - t
 
 
-def cpu_baseline(bufs, cam_uniforms, width, height, bounces, threads):
-    """The CPU restatement (oracle/, OpenMP) timed on a bounded sample of the same workload:
-    the same scene, camera and bounce count at reduced resolution."""
+def cpu_baseline(bufs, cam_uniforms, width, height, bounces, threads, budget_s):
+    """The CPU restatement (oracle/, OpenMP) timed on a bounded sample of the same workload: whole
+    frames at the full size, as many as fit the time budget (at least one)."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle as O
 
     u = np.concatenate([cam_uniforms[0], cam_uniforms[1], bufs.scene_min, bufs.scene_extent]).astype(np.float32)
     sc = O.OracleScene(bvh=bufs.bvh.tobytes(), tris=bufs.triangles.tobytes(), spheres=bufs.spheres.tobytes(),
                        mats=bufs.materials.tobytes(), uniforms=u)
-    w, h = width // 2, height // 2
     sc.render(64, 32, 0, bounces, threads=threads)  # warm up the thread pool
     t = time.time()
     frames = 0
     rays = 0
-    while time.time() - t < 8.0 or frames < 1:
-        _, cnt = sc.render(w, h, frames, bounces, want_counters=True, threads=threads)
+    while time.time() - t < budget_s or frames < 1:
+        _, cnt = sc.render(width, height, frames, bounces, want_counters=True, threads=threads)
         rays += cnt["rays"]
         frames += 1
     dt = time.time() - t
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{frames} frame(s) of the same scene/camera/bounces at {w}x{h} "
-                      f"({rays} rays in {dt:.1f} s, OpenMP C restatement of the reference shader)"}
+    out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "ms_per_frame": dt / frames * 1e3,
+           "sample": f"{frames} full frame(s) of the same scene/camera/bounces at {width}x{height} "
+                     f"({rays} rays in {dt:.1f} s, OpenMP C restatement of the reference shader)"}
+    # the reference's own shader on Mesa llvmpipe cannot travel to the GPU box; its timing on this
+    # very workload was taken where the goldens were generated and is committed with them
+    g = ROOT / "tests" / "golden" / "c4_sponza_synth_1920x1080_b4.json"
+    if g.exists():
+        rec = json.loads(g.read_text())
+        if (rec["w"], rec["h"], rec["bounces"]) == (width, height, bounces) and "llvmpipe_ms" in rec:
+            ms = float(np.median(rec["llvmpipe_ms"]))
+            out["reference_llvmpipe"] = {
+                "ms_per_frame": ms, "value": rec["rays_frame0"] / ms / 1e3, "unit": "Mrays/s",
+                "threads": rec["threads"], "where": "build container (8-core host), not this machine",
+                "what": "the reference's compute.glsl on Mesa llvmpipe, same scene, camera, size and bounces",
+                "source": str(g.relative_to(ROOT))}
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--bounces", type=int, default=4)
-    ap.add_argument("--detail", type=float, default=1.0)
-    ap.add_argument("--obj", default=None, help="render this OBJ (e.g. sponza_full.obj) instead of sponza_synth")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def roofline_block(name, args, kernel_ms, rays_per_launch, per_ray):
+    """Roofline of the dominant kernel.  `achieved` / `frac` follow the metric's definition
+    (algorithmic bytes in the reference's layouts / kernel time / HBM peak): a bytes-per-ray proxy,
+    most of which is served by LDS, L1 and L2.  `binding` says what the hardware counters show."""
+    n_node, n_tri, n_sph, hit_frac, rays_per_sample = per_ray
+    # algorithmic bytes per ray in the reference's layouts: 64 B per node visit, 64 B per triangle
+    # test, 32 B per sphere test, 12 B of material per hit, 16 B of image per pixel-sample
+    bytes_per_ray = 64.0 * n_node + 64.0 * n_tri + 32.0 * n_sph + 12.0 * hit_frac + 16.0 / rays_per_sample
+    achieved = rays_per_launch * bytes_per_ray / (kernel_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+           "frac_is": "algorithmic bytes (reference layouts) / kernel time / HBM peak; NOT the share of HBM "
+                      "bandwidth in use: see binding.hbm_counter_frac",
+           "algorithmic_bytes_per_launch": rays_per_launch * bytes_per_ray,
+           "kernel": "trace_kernel", "kernel_ms": kernel_ms,
+           "kernel_ms_how": "HIP events on the launch's stream, launches issued one at a time after the timed "
+                            "region; inside the timed region two launches overlap, so a kernel trace of this "
+                            "command shows longer per-kernel durations (RT_OVERLAP=0 gives matching ones)",
+           "bytes_per_ray": bytes_per_ray,
+           "per_ray": {"node_visits": n_node, "triangle_tests": n_tri, "sphere_tests": n_sph,
+                       "hit_fraction": hit_frac, "rays_per_pixel_sample": rays_per_sample}}
+    key = f"{name} {args.width}x{args.height} {args.bounces}b"
+    if PMC_FILE.exists():
+        t = json.loads(PMC_FILE.read_text())
+        if t.get("workload_key") == key:
+            c = t["counters"]
+            # FETCH_SIZE (KB) tallies a 128-byte line request as 64 B on gfx950 (calibrated for this access
+            # pattern with tools/microbench/fetch_calib.hip), hence the factor 2
+            traffic = (c["FETCH_SIZE"] * 2.0 + c["WRITE_SIZE"]) * 1024.0
+            out["traffic"] = traffic
+            pmc_ms = t["kernel_ms_in_pmc_run"]
+            cycles = c["GRBM_GUI_ACTIVE"] / 8.0           # the counter is summed over the 8 XCDs
+            simds, cus = 1024.0, 256.0
+            issue = t.get("valu_issue_cycles", 2.0)       # cycles one wave64 VALU instruction holds a SIMD's issue port
+            out["binding"] = {
+                "source": str(PMC_FILE.relative_to(ROOT)),
+                "hbm_counter_GBs": traffic / (pmc_ms * 1e-3) / 1e9,
+                "hbm_counter_frac": traffic / (pmc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "valu_busy": c["SQ_INSTS_VALU"] * issue / (simds * cycles),
+                "valu_lane_util": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]),
+                "vmem_issue": c["TA_TA_BUSY_sum"] / (cus * cycles) if "TA_TA_BUSY_sum" in c else None,
+                "l1_lookups_per_clk_per_cu": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (cus * cycles),
+                "waves_per_simd": c["SQ_WAVE_CYCLES"] * 4.0 / (simds * cycles),
+                "shader_clock_GHz": cycles / (pmc_ms * 1e-3) / 1e9,
+                "note": t.get("note", "")}
+    return out
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    # RT_BENCH_REHEARSE=1: every rank uses GPU 0 and the collectives run over gloo on host copies.
-    # For rehearsing the N>1 control flow on a one-GPU box; never a measurement.
-    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
-    dist = torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-
-        if rehearse:
-            local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    def collective(fn, t, **kw):
-        """Runs a torch.distributed collective on a device tensor (through host memory when rehearsing)."""
-        if rehearse:
-            h = t.cpu()
-            fn(h, **kw)
-            t.copy_(h)
-        else:
-            fn(t, **kw)
-
+def run_c4(args, r, comm, rank, world, name, bufs, build_s, rehearse):
+    """1080p frames: `rt_render` at one GPU, spp-sharded `rt_render_sum` + one reduce at N GPUs."""
     from raytracer_amd.camera import Camera
-    from raytracer_amd.renderer import Renderer
 
-    name, bufs, build_s = build_workload(args)
-    r = Renderer(device=local_rank, camera=Camera(), singleton=False)
-    r.update_size(args.width, args.height)
-    bufs.upload(r)
-    r.bounces = args.bounces
     npix = args.width * args.height
-
     # per-ray work of this workload, from one untimed instrumented frame (counter kernel variant)
     r.set_flags(stats=True)
     r.set_frame_index(0)
@@ -134,125 +156,225 @@ def main():
     r.sync()
     s0 = r.stats()
     rays0 = max(1, s0["rays"])
-    n_node, n_tri, n_sph = s0["nodes"] / rays0, s0["tri_tests"] / rays0, s0["sphere_tests"] / rays0
-    hit_frac = s0["hits"] / rays0
-    rays_per_sample = rays0 / npix
-    # algorithmic bytes per ray in the reference's layouts: 64 B per node visit, 64 B per triangle
-    # test, 32 B per sphere test, 12 B of material per hit, 16 B of image per pixel-sample
-    bytes_per_ray = 64.0 * n_node + 64.0 * n_tri + 32.0 * n_sph + 12.0 * hit_frac + 16.0 / rays_per_sample
+    per_ray = (s0["nodes"] / rays0, s0["tri_tests"] / rays0, s0["sphere_tests"] / rays0, s0["hits"] / rays0,
+               rays0 / npix)
     r.set_flags()
 
-    if world > 1:
-        sum_t = torch.zeros((args.height, args.width, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
-        sum_ptr = sum_t.data_ptr()
-    else:
-        sum_t, sum_ptr = None, None
-        r.clear_sum()
-
-    def step(i):
-        # frame index of this rank's i-th frame under spp sharding
-        r.render_sum(first_frame=i * world + rank, nframes=1, sum_ptr=sum_ptr)
-
-    def fence():
+    def timed_loop(step):
+        for i in range(args.warmup):
+            step(i)
         r.sync()
-        if world > 1:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    r.reset_stats()
-    if world > 1:
-        sum_t.zero_()
-        torch.cuda.synchronize()
-    else:
+        comm.barrier()
+        r.reset_stats()
         r.clear_sum()
-    fence()
-    trace_ms = 0.0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-        # the per-launch device time of the trace kernel is read after the timed region
-    r.sync()
-    if world > 1:
-        collective(dist.reduce, sum_t, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI, once per run
-    fence()
-    elapsed = time.perf_counter() - t0
+        r.sync()
+        comm.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        r.sync()
+        comm.reduce_sum_image(0)       # RCCL over xGMI, once per run (nothing to do at one GPU)
+        comm.barrier()
+        elapsed = time.perf_counter() - t0
+        rays = float(r.stats()["rays"])
+        return elapsed, rays
+
+    def sum_step(i):
+        r.render_sum(first_frame=i * world + rank, nframes=1)   # this rank's i-th frame under spp sharding
+
+    def frame_step(i):
+        r.set_frame_index(i)
+        r.render()                                              # dispatch + accumulate pass
+
+    sum_elapsed, sum_rays = timed_loop(sum_step)
     if rank == 0:
-        r.finalize_sum(args.steps * world, sum_ptr)
+        r.finalize_sum(args.steps * world)
         r.sync()
-    st = r.stats()
+    if world == 1:
+        r.reset_accumulation()
+        elapsed, rays = timed_loop(frame_step)
+    else:
+        elapsed, rays = sum_elapsed, sum_rays
+
     # device time of the dominant kernel, measured with HIP events on the library's own stream:
-    # time K single launches back to back outside the wall-clock region
+    # single launches, one at a time, outside the wall-clock region
     r.reset_stats()
     ev_ms = []
     for i in range(min(args.steps, 10)):
-        r.render_sum(first_frame=i * world + rank, nframes=1, sum_ptr=sum_ptr)
+        r.render_sum(first_frame=i * world + rank, nframes=1)
         r.sync()
         ev_ms.append(r.stats()["last_trace_ms"])
     kernel_ms = float(np.mean(ev_ms))
     rays_per_launch = r.stats()["rays"] / len(ev_ms)
 
-    my = np.array([elapsed, float(st["rays"])], dtype=np.float64)
-    if world > 1:
-        t = torch.tensor(my, device=f"cuda:{local_rank}")
-        tmax = t.clone()
-        collective(dist.all_reduce, tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        collective(dist.all_reduce, tsum, op=dist.ReduceOp.SUM)
-        elapsed_max, total_rays = float(tmax[0]), float(tsum[1])
+    tmax = comm.all_reduce([elapsed, sum_elapsed], "max")
+    tsum = comm.all_reduce([rays, sum_rays], "sum")
+    if rank != 0:
+        return None
+    out = {
+        "metric": "Mrays/s", "value": tsum[0] / tmax[0] / 1e6, "unit": "Mrays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": tmax[0] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" if not rehearse else "synthetic; REHEARSAL on one shared GPU with host-file collectives, not a measurement",
+        "config": {"workload": f"{name} {args.width}x{args.height} 1spp/frame {args.bounces} bounces, "
+                               f"default reference camera; stands in for sponza_full.obj (not distributed)",
+                   "step": ("one reference frame: compute dispatch + accumulate pass (rt_render)" if world == 1 else
+                            "one frame per GPU in linear-sum mode (rt_render_sum); one RCCL reduce per run, inside the timed region"),
+                   "triangles": int(bufs.triangles.shape[0]), "bvh_nodes": int(bufs.bvh.shape[0]),
+                   "rays_per_frame": rays_per_launch, "frames_per_step_per_gpu": 1,
+                   "parallelism": f"spp-sharded x{world}, scene replicated, 1 RCCL reduce (C ABI)" if world > 1 else "single GPU",
+                   "bvh_build_s": round(build_s, 3)},
+        "ms_per_frame": tmax[0] / args.steps * 1e3,
+        "sum_mode": {"value": tsum[1] / tmax[1] / 1e6, "unit": "Mrays/s", "ms_per_step": tmax[1] / args.steps * 1e3,
+                     "what": "the same loop through rt_render_sum (linear radiance sum, no sRGB encode, no accumulate "
+                             "pass): the per-GPU step of the multi-GPU runs, comparable across n_gpus"},
+        "roofline": roofline_block(name, args, kernel_ms, rays_per_launch, per_ray),
+    }
+    if not args.no_cpu_baseline and world == 1:
+        threads = min(16, os.cpu_count() or 1)
+        out["cpu_baseline"] = cpu_baseline(bufs, Camera().uniforms_f32(), args.width, args.height, args.bounces,
+                                           threads, args.cpu_seconds)
     else:
-        elapsed_max, total_rays = elapsed, float(st["rays"])
+        out["cpu_baseline"] = None
+    return out
 
-    if rank == 0:
-        achieved = rays_per_launch * bytes_per_ray / (kernel_ms * 1e-3) / 1e9
-        # memory-side bytes per launch come from separate rocprofv3 --pmc passes (they cannot be
-        # collected inside this process); the committed summary is used when it is for this workload
-        traffic = None
-        tj = ROOT / "profiles" / "r1" / "traffic.json"
-        key = f"{name} {args.width}x{args.height} {args.bounces}b"
-        if tj.exists():
-            t = json.loads(tj.read_text())
-            if t.get("workload_key") == key:
-                # FETCH_SIZE tallies a 128-byte line request as 64 B on gfx950 (calibrated for this
-                # access pattern with tools/microbench/fetch_calib.hip), hence the correction factor
-                traffic = (t["fetch_size_kb"] * t.get("fetch_correction", 2.0) + t["write_size_kb"]) * 1024.0
-        out = {
-            "metric": "Mrays/s", "value": total_rays / elapsed_max / 1e6, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearse else "synthetic; REHEARSAL on one shared GPU over gloo, not a measurement",
-            "config": {"workload": f"{name} {args.width}x{args.height} 1spp/frame {args.bounces} bounces, "
-                                   f"default reference camera; stands in for sponza_full.obj (not distributed)",
-                       "triangles": int(bufs.triangles.shape[0]), "bvh_nodes": int(bufs.bvh.shape[0]),
-                       "rays_per_frame": rays_per_launch, "frames_per_step_per_gpu": 1,
-                       "parallelism": f"spp-sharded x{world}, scene replicated, 1 RCCL reduce" if world > 1 else "single GPU",
-                       "bvh_build_s": round(build_s, 3)},
-            "ms_per_frame": kernel_ms,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": rays_per_launch * bytes_per_ray,
-                         "kernel": "trace_kernel", "kernel_ms": kernel_ms,
-                         "kernel_ms_how": "HIP events on the launch's stream, launches issued one at a time after "
-                                          "the timed region; inside the timed region two launches overlap, so a "
-                                          "kernel trace of this command shows longer per-kernel durations "
-                                          "(RT_OVERLAP=0 gives matching ones)",
-                         "bytes_per_ray": bytes_per_ray,
-                         "per_ray": {"node_visits": n_node, "triangle_tests": n_tri, "sphere_tests": n_sph,
-                                     "hit_fraction": hit_frac, "rays_per_pixel_sample": rays_per_sample}},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            threads = min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(bufs, Camera().uniforms_f32(), args.width, args.height, args.bounces,
-                                               threads)
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
-    r.close()
-    if world > 1:
-        dist.destroy_process_group()
+
+def c5_split(world: int):
+    """(tile shards, sample shards) of a strong-scaling run: two tile shards whenever the rank count
+    is even, the rest by samples; rank -> (rank % tiles, rank // tiles)."""
+    tiles = 2 if world % 2 == 0 else 1
+    return tiles, world // tiles
+
+
+def run_c5(args, r, comm, rank, world, name, bufs, build_s, rehearse):
+    """One 4K image of `--spp` samples per pixel split over the ranks by tiles and samples."""
+    spp = args.spp
+    tiles, phases = c5_split(world)
+    shard, phase = rank % tiles, rank // tiles
+
+    def image():
+        r.clear_sum()
+        t0 = time.perf_counter()
+        r.render_sum(first_frame=0, nframes=spp, shard=shard, nshards=tiles, frame_stride=phases, frame_phase=phase)
+        r.sync()
+        t_render = time.perf_counter() - t0
+        comm.reduce_sum_image(0)
+        t_reduce = time.perf_counter() - t0 - t_render
+        if rank == 0:
+            r.finalize_sum(spp)
+            r.sync()
+        return t_render, t_reduce, time.perf_counter() - t0
+
+    for _ in range(args.warmup):
+        image()
+    comm.barrier()
+    r.reset_stats()
+    r.sync()
+    comm.barrier()
+    t0 = time.perf_counter()
+    renders, reduces = [], []
+    for _ in range(args.steps):
+        a, b, _ = image()
+        renders.append(a)
+        reduces.append(b)
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    rays = float(r.stats()["rays"])
+    my_render = float(np.mean(renders))
+    tmax = comm.all_reduce([elapsed, my_render], "max")
+    tsum = comm.all_reduce([rays, my_render], "sum")
+    per_rank = comm.all_reduce([my_render * 1e3 if k == rank else 0.0 for k in range(world)], "sum")
+    if rank != 0:
+        return None
+    return {
+        "metric": "Mrays/s", "value": tsum[0] / tmax[0] / 1e6, "unit": "Mrays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": tmax[0] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" if not rehearse else "synthetic; REHEARSAL on one shared GPU with host-file collectives, not a measurement",
+        "config": {"workload": f"{name} {args.width}x{args.height} {spp} spp {args.bounces} bounces, default reference "
+                               f"camera; stands in for sponza_full.obj (not distributed)",
+                   "step": "one whole image: first launch -> reduce -> rank 0's finalised sRGB mean image",
+                   "triangles": int(bufs.triangles.shape[0]), "bvh_nodes": int(bufs.bvh.shape[0]),
+                   "parallelism": f"{tiles} tile shard(s) (64x64 Morton round-robin) x {phases} sample shard(s), scene "
+                                  f"replicated, 1 RCCL reduce (C ABI) per image",
+                   "bvh_build_s": round(build_s, 3)},
+        "time_to_image_ms": tmax[0] / args.steps * 1e3,
+        "per_rank_render_ms": [float(x) for x in per_rank],
+        "reduce_ms_rank0": float(np.mean(reduces)) * 1e3,
+        "imbalance_max_over_mean": float(tmax[1] / (tsum[1] / world)),
+        "roofline": None, "cpu_baseline": None,
+    }
+
+
+def worker(args):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) were started (WORLD_SIZE={world})")
+    # RT_BENCH_REHEARSE=1: every rank uses GPU 0 and the collectives go through host files.
+    # For rehearsing the N>1 control flow on a one-GPU box; never a measurement.
+    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
+
+    from raytracer_amd import dist as D
+    from raytracer_amd.camera import Camera
+    from raytracer_amd.renderer import Renderer
+
+    name, bufs, build_s = build_workload(args)
+    r = Renderer(device=0 if rehearse else local_rank, camera=Camera(), singleton=False)
+    try:
+        r.update_size(args.width, args.height)
+        bufs.upload(r)
+        r.bounces = args.bounces
+        comm = D.Comm(r, rank, world, rehearse=rehearse)
+        joined = comm.all_reduce([1.0], "sum")[0]
+        if int(round(joined)) != args.gpus:
+            raise SystemExit(f"bench.py: {joined:.0f} rank(s) joined, --gpus {args.gpus} expected")
+        run = run_c5 if args.config == "c5" else run_c4
+        out = run(args, r, comm, rank, world, name, bufs, build_s, rehearse)
+        if out is not None:
+            print(json.dumps(out), flush=True)
+        comm.barrier()
+    finally:
+        r.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["c4", "c5"], default="c4",
+                    help="c4: 1080p frames, weak scaling (default); c5: one 4K 256-spp image, strong scaling")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=256, help="c5: samples per pixel of the image")
+    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--obj", default=None, help="render this OBJ (e.g. sponza_full.obj) instead of sponza_synth")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the CPU baseline sample")
+    args = ap.parse_args()
+    c5 = args.config == "c5"
+    if args.steps is None:
+        args.steps = 2 if c5 else 20
+    if args.warmup is None:
+        args.warmup = 1 if c5 else 3
+    if args.width is None:
+        args.width = 3840 if c5 else 1920
+    if args.height is None:
+        args.height = 2160 if c5 else 1080
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the ranks here, before anything in this process touches a GPU
+        from raytracer_amd import dist as D
+
+        sys.exit(D.spawn_ranks([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], args.gpus))
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -142,6 +142,27 @@ int rt_clear_sum(rt_ctx *ctx, float *sum_rgba);
 int rt_finalize_sum(rt_ctx *ctx, const float *sum_rgba, uint32_t spp);
 
 /*
+ * Collectives for multi-GPU runs: one process per GPU, RCCL over xGMI, no framework needed (no
+ * counterpart in the reference).  Rank 0 draws an id with rt_comm_unique_id and hands its
+ * RT_COMM_ID_BYTES bytes to the other ranks by any means (a file, an environment variable, a
+ * socket); every rank then calls rt_comm_init on its context.  rt_comm_reduce_sum adds the ranks'
+ * linear sum images (`sum_rgba`: device pointer, W*H*4 f32, NULL = the context's own buffer; the
+ * same choice and image size on every rank) into rank `root`'s image; it first waits for the frames
+ * the context has in flight, and returns when the result is in place.  rt_comm_all_reduce_f64
+ * combines up to RT_COMM_MAX_SCALARS host doubles across ranks in place (timings, ray counts);
+ * rt_comm_barrier returns once every rank has called it.  librccl is opened at the first of these
+ * calls.  The communicator is released by rt_destroy.
+ */
+#define RT_COMM_ID_BYTES 128
+#define RT_COMM_MAX_SCALARS 64
+enum { RT_COMM_SUM = 0, RT_COMM_MAX = 1 };
+int rt_comm_unique_id(char id[RT_COMM_ID_BYTES]);
+int rt_comm_init(rt_ctx *ctx, int rank, int world, const char id[RT_COMM_ID_BYTES]);
+int rt_comm_reduce_sum(rt_ctx *ctx, float *sum_rgba, int root);
+int rt_comm_all_reduce_f64(rt_ctx *ctx, double *values, int count, int op);
+int rt_comm_barrier(rt_ctx *ctx);
+
+/*
  * One frame without any allocation.  No counterpart in the reference; it is for callers that
  * cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc.  A variant of rt_render (same kernels, same results bit for bit) that takes no

@@ -48,6 +48,9 @@ def lib():
         L.rto_render.restype = C.c_int
         L.rto_render.argtypes = [C.POINTER(RtoScene), C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,
                                  C.c_void_p, C.POINTER(RtoCounters), C.c_int]
+        L.rto_render_window.restype = C.c_int
+        L.rto_render_window.argtypes = [C.POINTER(RtoScene), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_float, C.c_float, C.c_void_p, C.c_int]
         L.rto_accumulate.restype = None
         L.rto_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]
         for name in ("rto_sin", "rto_cos", "rto_exp2", "rto_log2", "rto_srgb_to_linear", "rto_linear_to_srgb"):
@@ -110,6 +113,19 @@ class OracleScene:
         if want_counters:
             out.append({n: getattr(cnt, n) for n, _ in RtoCounters._fields_ if n != "pad"})
         return out[0] if len(out) == 1 else tuple(out)
+
+
+def _render_window(self, w, h, x0, y0, ww, wh, frame, bounces, threads=0):
+    """Pixels [x0, x0+ww) x [y0, y0+wh) of the w x h frame, as a dense (wh, ww, 4) image."""
+    img = np.zeros((wh, ww, 4), dtype=np.float32)
+    rc = lib().rto_render_window(C.byref(self.s), w, h, x0, y0, ww, wh, float(frame), float(bounces),
+                                 img.ctypes.data, threads)
+    if rc != 0:
+        raise RuntimeError(f"rto_render_window failed rc={rc}")
+    return img
+
+
+OracleScene.render_window = _render_window
 
 
 def accumulate(sample: np.ndarray, old: np.ndarray, frames: float) -> np.ndarray:

@@ -111,6 +111,9 @@ struct rt_ctx {
     int pipeline = 0;
     rt::WaveQueues q = {{nullptr, nullptr}, nullptr, nullptr};
     uint64_t pixel_samples = 0;  // pixel-samples queued since the last rt_reset_stats
+    void *comm = nullptr;  // RCCL communicator (rt_comm_init)
+    int comm_rank = 0, comm_world = 1;
+    double *comm_scratch = nullptr;
     uint32_t extend_waves = 8192;
     uint32_t refill_threshold = 16;
     uint32_t leaf_threshold = 8;
@@ -382,6 +385,23 @@ int end_timed(rt_ctx *c) {
 
 }  // namespace
 
+int rt::ctx_device(rt_ctx *c) { return c->device; }
+void *rt::ctx_comm(rt_ctx *c) { return c->comm; }
+void rt::ctx_set_comm(rt_ctx *c, void *comm, int rank, int world) {
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_world = world;
+}
+double *rt::ctx_comm_scratch(rt_ctx *c) { return c->comm_scratch; }
+int rt::ctx_join_for_collective(rt_ctx *c, hipStream_t *stream, float **own_sum, size_t *nfloats) {
+    if (int rc = join(c)) return rc;
+    c->main_dirty = true;  // the collective reads and writes images on `stream`
+    *stream = c->stream;
+    *own_sum = reinterpret_cast<float *>(c->sum);
+    *nfloats = (size_t)c->W * c->H * 4;
+    return 0;
+}
+
 extern "C" {
 
 const char *rt_last_error(void) { return g_err.c_str(); }
@@ -401,6 +421,7 @@ static int create_impl(rt_ctx *c, int device) {
     if (const char *e = getenv("RT_OVERLAP")) c->overlap = atoi(e) != 0;
     HIP_TRY(hipMalloc((void **)&c->counters, sizeof(rt::Counters) * rt::kCounterStripes));
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(rt::Counters) * rt::kCounterStripes, c->stream));
+    HIP_TRY(hipMalloc((void **)&c->comm_scratch, sizeof(double) * RT_COMM_MAX_SCALARS));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     // persistent traversal kernel: one 64-lane workgroup per wave slot (32 per CU)
@@ -446,6 +467,8 @@ int rt_destroy(rt_ctx *c) {
     for (int b = 0; b < 2; b++)
         if (c->tstream[b]) (void)hipStreamSynchronize(c->tstream[b]);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    rt::comm_destroy(c->comm);
+    if (c->comm_scratch) (void)hipFree(c->comm_scratch);
     for (RawBuffer *b : {&c->spheres, &c->planes, &c->boxes, &c->mats, &c->nodes, &c->tris}) {
         if (b->raw) (void)hipFree(b->raw);
         if (b->packed) (void)hipFree(b->packed);

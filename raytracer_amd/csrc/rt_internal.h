@@ -6,6 +6,8 @@
 
 #include <string>
 
+struct rt_ctx;
+
 namespace rt {
 
 // ---- device-side record layouts (what the repack kernels produce) -------------------------
@@ -87,6 +89,16 @@ void launch_accumulate(const float4 *sample, float4 *acc, size_t npixels, float 
 // acc = srgb(sum / spp)
 void launch_fold_sum(float4 *target, float4 *part, size_t npixels, hipStream_t s);
 void launch_finalize_sum(const float4 *sum, float4 *acc, size_t npixels, uint32_t spp, hipStream_t s);
+
+// ---- what rt_comm.cpp needs from a context (rt_api.cpp) -------------------------------------
+int ctx_device(rt_ctx *c);
+void *ctx_comm(rt_ctx *c);                     // the RCCL communicator, or null
+void ctx_set_comm(rt_ctx *c, void *comm, int rank, int world);
+double *ctx_comm_scratch(rt_ctx *c);           // device buffer of RT_COMM_MAX_SCALARS doubles
+// joins the trace streams (folds pending sums) and hands out the main stream, the context's own
+// sum image and its size in floats
+int ctx_join_for_collective(rt_ctx *c, hipStream_t *stream, float **own_sum, size_t *nfloats);
+void comm_destroy(void *comm);                 // rt_comm.cpp
 
 // message rt_last_error() returns on the calling thread (rt_api.cpp)
 void set_last_error(const std::string &message);

@@ -9,11 +9,22 @@ pixel-sample is independent (its RNG is keyed by pixel and frame index only):
   (``tile_owner``), the rule the kernels apply when ``rt_render_sum`` is given nshards > 1.
 
 Each rank adds linear radiance into its own fp32 RGBA sum image; the images are combined once
-per run with a sum-reduce to rank 0 (``torch.distributed.reduce``: RCCL over xGMI on GPUs, gloo
-on CPU), after which rank 0 divides by the sample count and sRGB-encodes.
+per run with a sum-reduce to rank 0, after which rank 0 divides by the sample count and
+sRGB-encodes.  On GPUs the reduce is RCCL over xGMI called through the C ABI (``rt_comm_*`` in
+include/rt_mi355x.h, wrapped by ``Comm`` below); no framework is involved.  The only thing ranks
+must exchange beforehand is RCCL's 128-byte id, which goes through a directory all ranks of the
+node can see (``Rendezvous``).  ``spawn_ranks`` starts one process per GPU when no launcher did.
 """
 
 from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+import time
+from pathlib import Path
 
 import numpy as np
 
@@ -63,3 +74,156 @@ def finalize_mean_srgb(sum_rgba: np.ndarray, spp: int) -> np.ndarray:
     lin = np.asarray(sum_rgba, dtype=np.float32)[..., :3] / np.float32(spp)
     out = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * np.power(np.maximum(lin, 0), 1 / 2.4) - 0.055)
     return np.concatenate([out, np.ones(out.shape[:-1] + (1,), out.dtype)], axis=-1).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# launching and rendezvous (host side only: nothing here touches a GPU)
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(argv: list[str], world: int, extra_env: dict | None = None, timeout: float | None = None) -> int:
+    """Starts `world` fresh processes running `argv`, one per GPU, with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT / RT_RDZV_DIR set, relays rank 0's stdout, and returns 0
+    only if every rank exited with 0.  The caller must not have initialised the GPU."""
+    rdzv = tempfile.mkdtemp(prefix="rt_mi355x_rdzv_")
+    procs = []
+    out_path = Path(rdzv) / "rank0.stdout"
+    try:
+        with open(out_path, "wb") as out0:
+            for rank in range(world):
+                env = dict(os.environ)
+                env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                            "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": env.get("MASTER_PORT", "29511"),
+                            "RT_RDZV_DIR": rdzv,
+                            "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+                env.update(extra_env or {})
+                procs.append(subprocess.Popen(argv, env=env, stdout=out0 if rank == 0 else subprocess.DEVNULL))
+            # a rank that dies would leave the others waiting in a collective for ever: watch them all
+            t0, failed = time.time(), []
+            while True:
+                codes = [p.poll() for p in procs]
+                failed = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+                if failed or all(c == 0 for c in codes):
+                    break
+                if timeout is not None and time.time() - t0 > timeout:
+                    failed = [("timeout", timeout)]
+                    break
+                time.sleep(0.02)
+        sys.stdout.write(out_path.read_text(errors="replace"))
+        sys.stdout.flush()
+        if failed:
+            print(f"spawn_ranks: ranks failed out of {world} (rank, exit code): {failed}", file=sys.stderr)
+            return 1
+        return 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()  # exactly the processes started here
+                p.wait()
+        for f in Path(rdzv).glob("*"):
+            f.unlink()
+        for f in Path(rdzv).glob(".*"):
+            f.unlink()
+        os.rmdir(rdzv)
+
+
+def rendezvous_dir() -> Path:
+    """Directory shared by the ranks of this run: RT_RDZV_DIR when spawn_ranks launched them,
+    otherwise derived from what all ranks of one launcher have in common (the launcher's pid and
+    start time, and MASTER_PORT)."""
+    d = os.environ.get("RT_RDZV_DIR")
+    if d:
+        return Path(d)
+    ppid = os.getppid()
+    try:
+        start = Path(f"/proc/{ppid}/stat").read_text().rsplit(")", 1)[1].split()[19]
+    except OSError:
+        start = "0"
+    path = Path(tempfile.gettempdir()) / f"rt_mi355x_rdzv_{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}"
+    path.mkdir(exist_ok=True)
+    return path
+
+
+class Rendezvous:
+    """Write-once named blobs in a directory every rank can see."""
+
+    def __init__(self, directory: Path | None = None) -> None:
+        self.dir = Path(directory) if directory is not None else rendezvous_dir()
+
+    def publish(self, name: str, data: bytes) -> None:
+        tmp = self.dir / f".{name}.{os.getpid()}.tmp"
+        tmp.write_bytes(data)
+        os.replace(tmp, self.dir / name)  # atomic: a reader sees all of it or none
+
+    def wait(self, name: str, timeout: float = 120.0) -> bytes:
+        path, t0 = self.dir / name, time.time()
+        while not path.exists():
+            if time.time() - t0 > timeout:
+                raise TimeoutError(f"rendezvous: {path} did not appear within {timeout:.0f} s "
+                                   "(did every rank start?)")
+            time.sleep(0.005)
+        return path.read_bytes()
+
+
+class Comm:
+    """The run's collectives for one rank.  `rehearse=True` (several ranks sharing one GPU, where
+    RCCL refuses to form a communicator) moves the same data through host files instead; it exists
+    to rehearse the control flow and is never a measurement."""
+
+    def __init__(self, renderer, rank: int, world: int, rdzv: Rendezvous | None = None, rehearse: bool = False,
+                 tag: str = "run") -> None:
+        from . import _lib
+
+        self.r, self.rank, self.world, self.rehearse, self.tag = renderer, rank, world, rehearse, tag
+        self.rdzv = rdzv if rdzv is not None else Rendezvous()
+        self._seq = 0
+        self._L = _lib.load()
+        if world == 1 or rehearse:
+            return
+        if rank == 0:
+            buf = C.create_string_buffer(_lib.RT_COMM_ID_BYTES)
+            _lib.check(self._L.rt_comm_unique_id(buf))
+            self.rdzv.publish(f"{tag}.rccl_id", buf.raw)
+            ident = buf.raw
+        else:
+            ident = self.rdzv.wait(f"{tag}.rccl_id")
+        _lib.check(self._L.rt_comm_init(renderer._ctx, rank, world, ident))
+
+    # -- file-based stand-ins used when rehearsing ------------------------------------------------
+    def _exchange(self, payload: np.ndarray) -> list[np.ndarray]:
+        self._seq += 1
+        self.rdzv.publish(f"{self.tag}.x{self._seq}.r{self.rank}", payload.tobytes())
+        return [np.frombuffer(self.rdzv.wait(f"{self.tag}.x{self._seq}.r{k}"), dtype=payload.dtype).reshape(payload.shape)
+                for k in range(self.world)]
+
+    def all_reduce(self, values, op: str = "sum") -> np.ndarray:
+        """Element-wise sum or max of a few float64 values over all ranks."""
+        from . import _lib
+
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        if self.world == 1:
+            return v
+        if self.rehearse:
+            parts = self._exchange(v)
+            return np.sum(parts, axis=0) if op == "sum" else np.max(parts, axis=0)
+        _lib.check(self._L.rt_comm_all_reduce_f64(self.r._ctx, v.ctypes.data_as(C.POINTER(C.c_double)), v.size,
+                                                  _lib.RT_COMM_SUM if op == "sum" else _lib.RT_COMM_MAX))
+        return v
+
+    def barrier(self) -> None:
+        self.all_reduce([1.0])
+
+    def reduce_sum_image(self, root: int = 0) -> None:
+        """Adds every rank's own linear sum image into rank `root`'s (one collective per run)."""
+        from . import _lib
+
+        if self.world == 1:
+            return
+        if self.rehearse:
+            img = self.r.read_sum()
+            parts = self._exchange(img)
+            if self.rank == root:
+                total = parts[0].copy()
+                for p_ in parts[1:]:
+                    total = total + p_
+                self.r.write_sum(total)
+            return
+        _lib.check(self._L.rt_comm_reduce_sum(self.r._ctx, None, root))

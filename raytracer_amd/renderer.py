@@ -194,6 +194,27 @@ class Renderer:
         _lib.check(self._L.rt_sum_buffer(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def _hip_copy(self, dst, src, nbytes: int, kind: int) -> None:
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        if hip.hipMemcpy(dst, src, nbytes, kind) != 0:
+            raise RuntimeError("hipMemcpy of the sum image failed")
+
+    def read_sum(self) -> np.ndarray:
+        """(H, W, 4) float32 copy of the context's linear sum image (rgb sums, alpha = sample count)."""
+        self.sync()
+        p, n = self.sum_buffer()
+        out = np.empty((self._height, self._width, 4), np.float32)
+        self._hip_copy(out.ctypes.data, C.c_void_p(p), n, 2)
+        return out
+
+    def write_sum(self, img) -> None:
+        self.sync()
+        p, n = self.sum_buffer()
+        a = np.ascontiguousarray(img, dtype=np.float32)
+        assert a.nbytes == n
+        self._hip_copy(C.c_void_p(p), a.ctypes.data, n, 1)
+
     def close(self) -> None:
         if self._ctx:
             self._L.rt_destroy(self._ctx)
