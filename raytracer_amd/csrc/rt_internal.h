@@ -15,7 +15,8 @@ namespace rt {
 //   [0] min_x[4] [1] max_x[4] [2] min_y[4] [3] max_y[4] [4] min_z[4] [5] max_z[4]
 //   [6] metadata[4] (bit pattern, type<<30 | index)   [7] unused
 // Triangle: 64 B = 4 x float4:
-//   [0] v0.xyz, material   [1] e1.xyz, n.x   [2] e2.xyz, n.y   [3] n.z, 0, 0, 0
+//   [0] v0.xyz, 0   [1] e1.xyz, 0   [2] e2.xyz, 0   [3] normal.xyz, material
+//   (the test reads 48 B, an accepted hit one 16-byte record more)
 // Sphere: 32 B = 2 x float4:   [0] centre.xyz, radius^2   [1] material, 0, 0, 0
 // Material: 64 B = 4 x float4:
 //   [0] emitted.rgb (emission*strength), smoothness   [1] specular tint.rgb, transmission

@@ -15,14 +15,15 @@ namespace rt {
 
 #define RT_BLOCK 256
 #ifndef RT_LDS_TOP
-#define RT_LDS_TOP 85      // megakernel: number of leading (breadth-first) nodes kept in LDS per workgroup (85 = four levels); 0 = none
+#define RT_LDS_TOP 109     // number of leading (breadth-first) nodes kept in LDS per workgroup: four levels (85) plus what fits in the
+                           // 20 KB a workgroup may use while 8 of them share a CU; 0 = none
 #endif
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 4   // megakernel: wavefronts per workgroup (each an 8x8 quarter of a 16x16 tile); 1, 2, 4 or 8
 #endif
 #define RT_TRACE_BLOCK (64 * RT_TRACE_WAVES)
 #ifndef RT_TOP_STRIDE
-#define RT_TOP_STRIDE 9    // float4 per cached node: 144 B, so that 16 lanes on 16 different nodes use 16 different bank groups
+#define RT_TOP_STRIDE 7    // float4 per cached node: 112 B; 7 is odd, so 16 lanes on 16 consecutive nodes use 16 different bank groups
 #endif
 // Traversal stack: the first RT_STACK_LDS entries of every lane live in LDS (lane-contiguous, so
 // conflict-free); deeper entries spill to per-lane private memory.  The reference's own array
@@ -37,34 +38,11 @@ namespace rt {
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 8  // megakernel: waves per SIMD the register allocator must leave room for
 #endif
-// Node records in device memory: 0 = 128-byte pre-decoded fp32 node (7 x 16-byte requests per
-// visit, no decode arithmetic); 1 = the reference's 64-byte quantised node decoded on the fly
-// (4 requests per visit, two nodes per 128-byte line, +170 VALU operations per visit).  Both give
-// identical results; the kernel is limited by VALU issue rather than by cache requests, and the
-// pre-decoded form measured 9 % faster on the 265 k-triangle scene.
-#ifndef RT_NODE64
-#define RT_NODE64 0
-#endif
-#ifndef RT_LANE_PROFILE
-#define RT_LANE_PROFILE 0  // diagnostic build: with statistics on, box_tests / hits / stack_overflows
-#endif                     // count wavefront-level executions of a node step / leaf test / bounce
-#ifndef RT_XCD_MAP
-#define RT_XCD_MAP 2  // megakernel tile placement: 0 round-robin tiles, 1 one band of tiles per XCD, 2 macro tiles dealt to XCDs
-#endif
 #ifndef RT_MACRO
-#define RT_MACRO 2    // RT_XCD_MAP 2: macro tile = RT_MACRO x RT_MACRO tiles of 16x16 pixels
-#endif
-#ifndef RT_REGTOP
-#define RT_REGTOP 0  // megakernel: keep the next node to visit in a register when the last visit pushed one (measured: no gain)
-#endif
-#ifndef RT_WARM
-#define RT_WARM 0    // with RT_REGTOP: request the next node's cache line before the leaf tests
-#endif
-#ifndef RT_PREFETCH
-#define RT_PREFETCH 0  // megakernel: fetch the next node before intersecting the pending leaves
+#define RT_MACRO 2    // megakernel tile placement: macro tile = RT_MACRO x RT_MACRO tiles of 16x16 pixels, dealt to the XCDs in turn
 #endif
 #ifndef RT_EXT_STACK_LDS
-#define RT_EXT_STACK_LDS 16  // traversal kernel of the wavefront pipeline: 4 KB of LDS per wavefront
+#define RT_EXT_STACK_LDS 8   // traversal kernel of the wavefront pipeline: 2 KB of LDS stack per wavefront
 #endif
 #ifndef RT_EXTEND_MIN_WAVES
 #define RT_EXTEND_MIN_WAVES 8
@@ -179,20 +157,6 @@ __device__ __forceinline__ float l2s(float c) {
     return (1.0f + 0.055f) * d_pow(c, 1.0f / 2.4f) - 0.055f;
 }
 
-// Child box coordinate from its 16-bit code, compute.glsl:244-261:
-//   f = float(q) / 65535.0 ; coord = scene_min + f * scene_extent
-// The IEEE quotient is produced without a divide: with c = RN(1/65535), q0 = q*c,
-// r = fma(-q0, 65535, q), f = fma(r, c, q0) equals q/65535 correctly rounded for every
-// q in [0, 65535] (checked exhaustively in tests/test_decode_exact.py).
-__device__ __forceinline__ float dequant(uint32_t q, float mn, float ex) {
-    const float c = 1.0f / 65535.0f;
-    float qf = (float)q;
-    float q0 = qf * c;
-    float r = __builtin_fmaf(-q0, 65535.0f, qf);
-    float f = __builtin_fmaf(r, c, q0);
-    return mn + f * ex;
-}
-
 // compute.glsl:749-760
 __device__ __forceinline__ float draw(uint32_t &s) {
     s = (s ^ 61u) ^ (s >> 16);
@@ -208,8 +172,7 @@ __device__ __forceinline__ float draw(uint32_t &s) {
 // Every derived value is computed with exactly the operations the shader would apply per use,
 // so hoisting it here cannot change a result bit.
 // ------------------------------------------------------------------------------------------
-// BVH node.  RT_NODE64: kept in the reference's 64-byte form (plus the all-zero sentinel).
-// Otherwise decoded once here, compute.glsl:244-261: f = float(q)/65535.0 ; coord = scene_min + f*scene_extent
+// BVH node, decoded once here, compute.glsl:244-261: f = float(q)/65535.0 ; coord = scene_min + f*scene_extent
 // Device record i is built from source node order[i]; child indices are rewritten with
 // rank[] (rank[order[i]] = i).  The renumbering puts the nodes in breadth-first order from the
 // root, so the top levels of the tree are the first records; nothing outside the traversal ever
@@ -230,11 +193,6 @@ __global__ void repack_nodes_kernel(const uint32_t *__restrict__ src, uint32_t n
         const uint32_t idx = w[k] & 0x3FFFFFFFu;
         if ((w[k] >> 30) == 3u && idx < n && rank) w[k] = 0xC0000000u | rank[idx];
     }
-#if RT_NODE64
-    uint4 *o = reinterpret_cast<uint4 *>(dst) + (size_t)i * 4;
-#pragma unroll
-    for (int k = 0; k < 4; k++) o[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
-#else
     const float mn[3] = {smin.x, smin.y, smin.z}, ex[3] = {sext.x, sext.y, sext.z};
     float lo[3][4], hi[3][4];
 #pragma unroll
@@ -254,7 +212,6 @@ __global__ void repack_nodes_kernel(const uint32_t *__restrict__ src, uint32_t n
     }
     o[6] = make_float4(u2f(w[12]), u2f(w[13]), u2f(w[14]), u2f(w[15]));
     o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
 }
 
 // Triangle, compute.glsl:880-881: edge1 = v1 - v0, edge2 = v2 - v0
@@ -268,10 +225,11 @@ __global__ void repack_tris_kernel(const uint32_t *__restrict__ src, uint32_t n,
        v2 = V(u2f(w[8]), u2f(w[9]), u2f(w[10]));
     v3 e1 = v1 - v0, e2 = v2 - v0;
     float4 *o = dst + (size_t)i * kTriVec;
-    o[0] = make_float4(v0.x, v0.y, v0.z, u2f(w[3]));
-    o[1] = make_float4(e1.x, e1.y, e1.z, u2f(w[12]));
-    o[2] = make_float4(e2.x, e2.y, e2.z, u2f(w[13]));
-    o[3] = make_float4(u2f(w[14]), 0.f, 0.f, 0.f);
+    // the intersection test reads records 0..2, the accepted hit only record 3
+    o[0] = make_float4(v0.x, v0.y, v0.z, 0.f);
+    o[1] = make_float4(e1.x, e1.y, e1.z, 0.f);
+    o[2] = make_float4(e2.x, e2.y, e2.z, 0.f);
+    o[3] = make_float4(u2f(w[12]), u2f(w[13]), u2f(w[14]), u2f(w[3]));
 }
 
 __global__ void repack_spheres_kernel(const uint32_t *__restrict__ src, uint32_t n, float4 *__restrict__ dst) {
@@ -407,11 +365,6 @@ __device__ __forceinline__ bool box_distance(v3 O, v3 D, v3 b0, v3 b1, float &t_
     return true;
 }
 
-// true in exactly one of the lanes that execute it together
-__device__ __forceinline__ bool first_active_lane() {
-    return (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(1));
-}
-
 #define CSWAP(ka, kb, ma, mb, va, vb)  \
     {                                  \
         bool sw_ = (kb < ka);          \
@@ -438,31 +391,40 @@ struct LeafList {
 // Raw words of one node as loaded, before any arithmetic: the loads can be issued early and
 // waited for only where node_test first touches them.
 struct NodeRegs {
-#if RT_NODE64
-    uint4 ax, ay, az, mw;
-#else
     float4 lox, hix, loy, hiy, loz, hiz, mt;
-#endif
 };
+
+// The workgroup's LDS copy of the first nodes, typed as an LDS pointer: reads through it are LDS
+// instructions (ds_read_b128), which bypass the vector-memory (texture address / data) path that
+// bounds this kernel.  Through a generic pointer the compiler merges the LDS and the global case
+// into flat loads, and every lane of those goes through the texture-address unit.
+typedef float vec4f __attribute__((ext_vector_type(4)));  // plain vector: may carry an address space
+using LdsTop = const __attribute__((address_space(3))) vec4f *;
+using GlobalNodes = const __attribute__((address_space(1))) vec4f *;
+__device__ __forceinline__ float4 ld4(LdsTop p) {
+    vec4f v = *p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 ld4(GlobalNodes p) {
+    vec4f v = *p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 
 // Issues the loads of node ni.  TOP > 0: the first TOP nodes (breadth-first numbering, i.e. the top
 // levels of the tree) are read from the workgroup's LDS copy `top` instead of through the vector
 // memory pipeline, which is what bounds this kernel.
 template <int TOP = 0>
-__device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeRegs &nd, const float4 *top = nullptr) {
+__device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeRegs &nd, LdsTop top = nullptr) {
     ni = min(ni, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
-#if RT_NODE64
-    const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes) + (size_t)ni * 4;
-    nd.ax = np[0], nd.ay = np[1], nd.az = np[2], nd.mw = np[3];
-#else
     if (TOP > 0 && ni < (uint32_t)TOP) {
-        const float4 *tp = top + ni * RT_TOP_STRIDE;
-        nd.lox = tp[0], nd.hix = tp[1], nd.loy = tp[2], nd.hiy = tp[3], nd.loz = tp[4], nd.hiz = tp[5], nd.mt = tp[6];
+        LdsTop tp = top + ni * RT_TOP_STRIDE;
+        nd.lox = ld4(tp), nd.hix = ld4(tp + 1), nd.loy = ld4(tp + 2), nd.hiy = ld4(tp + 3), nd.loz = ld4(tp + 4),
+        nd.hiz = ld4(tp + 5), nd.mt = ld4(tp + 6);
         return;
     }
-    const float4 *np = sc.nodes + (size_t)ni * kNodeVec;
-    nd.lox = np[0], nd.hix = np[1], nd.loy = np[2], nd.hiy = np[3], nd.loz = np[4], nd.hiz = np[5], nd.mt = np[6];
-#endif
+    GlobalNodes np = (GlobalNodes)sc.nodes + (size_t)ni * kNodeVec;
+    nd.lox = ld4(np), nd.hix = ld4(np + 1), nd.loy = ld4(np + 2), nd.hiy = ld4(np + 3), nd.loz = ld4(np + 4),
+    nd.hiz = ld4(np + 5), nd.mt = ld4(np + 6);
 }
 
 // Pops the node index on top of the stack.
@@ -480,7 +442,7 @@ __device__ __forceinline__ uint32_t stack_pop(int &sp, const uint32_t *stack, co
 // Pops the next node index and issues its loads.
 template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP = 0>
 __device__ __forceinline__ void node_fetch(const DevScene &sc, int &sp, const uint32_t *stack, const uint32_t *spill,
-                                           NodeRegs &nd, LaneStats &st, const float4 *top = nullptr) {
+                                           NodeRegs &nd, LaneStats &st, LdsTop top = nullptr) {
     if (STATS) {
         st.max_sp = max(st.max_sp, (uint32_t)sp);
         st.nodes++;
@@ -489,30 +451,11 @@ __device__ __forceinline__ void node_fetch(const DevScene &sc, int &sp, const ui
 }
 
 // Slab tests, sort, pushes and leaf list for a fetched node.
-// REGTOP: the nearest visited inner child -- the node the next iteration pops -- is handed back in
-// `next` (have_next = true) instead of going through the stack, whenever the pushes took the
-// branch-free path; the caller then skips the pop.
-template <bool STATS, int STRIDE, int LDS_DEPTH, bool REGTOP = false>
+template <bool STATS, int STRIDE, int LDS_DEPTH>
 __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd, v3 O, v3 ID, float best, int &sp,
-                                          uint32_t *stack, uint32_t *spill, LeafList &ll, LaneStats &st,
-                                          uint32_t *next = nullptr, bool *have_next = nullptr) {
-#if RT_NODE64
-    uint4 ax = nd.ax, ay = nd.ay, az = nd.az, mw = nd.mw;
-    float4 lox, hix, loy, hiy, loz, hiz;
-#define DQ(c)                                                 \
-    lox.c = dequant(ax.c & 0xFFFFu, sc.smin[0], sc.sext[0]);  \
-    hix.c = dequant(ax.c >> 16, sc.smin[0], sc.sext[0]);      \
-    loy.c = dequant(ay.c & 0xFFFFu, sc.smin[1], sc.sext[1]);  \
-    hiy.c = dequant(ay.c >> 16, sc.smin[1], sc.sext[1]);      \
-    loz.c = dequant(az.c & 0xFFFFu, sc.smin[2], sc.sext[2]);  \
-    hiz.c = dequant(az.c >> 16, sc.smin[2], sc.sext[2]);
-    DQ(x) DQ(y) DQ(z) DQ(w)
-#undef DQ
-    uint32_t m0 = mw.x, m1 = mw.y, m2 = mw.z, m3 = mw.w;
-#else
+                                          uint32_t *stack, uint32_t *spill, LeafList &ll, LaneStats &st) {
     float4 lox = nd.lox, hix = nd.hix, loy = nd.loy, hiy = nd.hiy, loz = nd.loz, hiz = nd.hiz;
     uint32_t m0 = f2u(nd.mt.x), m1 = f2u(nd.mt.y), m2 = f2u(nd.mt.z), m3 = f2u(nd.mt.w);
-#endif
     float k0, k1, k2, k3;
     uint32_t v0, v1, v2, v3_;  // 1 = the child is visited
     // compute.glsl:186-208, one child per macro expansion
@@ -552,20 +495,9 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
         w += in2 * STRIDE;
         w[0] = m1 & 0x3FFFFFFFu;
         w += in1 * STRIDE;
-        if (REGTOP) {
-            // the last child pushed is the lowest k that is visited and inner; it stays in a
-            // register (its row, if written at all, is above the new top)
-            const uint32_t np_ = in3 + in2 + in1 + in0;
-            const uint32_t nx = in0 ? m0 : (in1 ? m1 : (in2 ? m2 : m3));
-            *next = nx & 0x3FFFFFFFu;
-            *have_next = np_ != 0u;
-            sp += (int)np_ - (np_ != 0u ? 1 : 0);
-        } else {
-            w[0] = m0 & 0x3FFFFFFFu;
-            sp += (int)(in3 + in2 + in1 + in0);
-        }
+        w[0] = m0 & 0x3FFFFFFFu;
+        sp += (int)(in3 + in2 + in1 + in0);
     } else {
-        if (REGTOP) *have_next = false;
 #define PUSH_INNER(IN, META)                                                                      \
     if (IN) {                                                                                     \
         uint32_t idx = META & 0x3FFFFFFFu;                                                        \
@@ -604,7 +536,7 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
 
 template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP = 0>
 __device__ __forceinline__ void node_part(const DevScene &sc, v3 O, v3 ID, float best, int &sp, uint32_t *stack,
-                                          uint32_t *spill, LeafList &ll, LaneStats &st, const float4 *top = nullptr) {
+                                          uint32_t *spill, LeafList &ll, LaneStats &st, LdsTop top = nullptr) {
     NodeRegs nd;
     node_fetch<STATS, STRIDE, LDS_DEPTH, TOP>(sc, sp, stack, spill, nd, st, top);
     node_test<STATS, STRIDE, LDS_DEPTH>(sc, nd, O, ID, best, sp, stack, spill, ll, st);
@@ -646,18 +578,10 @@ __device__ __forceinline__ void leaf_one(const DevScene &sc, v3 O, v3 D, float &
 template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP = 0>
 __device__ __forceinline__ void node_step(const DevScene &sc, v3 O, v3 D, v3 ID, float &best, uint32_t &best_code,
                                           int &sp, uint32_t *stack, uint32_t *spill, LaneStats &st,
-                                          const float4 *top = nullptr) {
+                                          LdsTop top = nullptr) {
     LeafList ll;
     node_part<STATS, STRIDE, LDS_DEPTH, TOP>(sc, O, ID, best, sp, stack, spill, ll, st, top);
-#if RT_LANE_PROFILE
-    if (STATS && first_active_lane()) st.box++;
-    while (ll.n > 0) {
-        if (STATS && first_active_lane()) st.hits++;
-        leaf_one<STATS>(sc, O, D, best, best_code, ll, st);
-    }
-#else
     while (ll.n > 0) leaf_one<STATS>(sc, O, D, best, best_code, ll, st);
-#endif
 }
 
 // Surface attributes of the accepted primitive, derived from (O, D, t, code) exactly as the
@@ -668,9 +592,9 @@ __device__ __forceinline__ void hit_attributes(const DevScene &sc, v3 O, v3 D, f
     pos = O + D * t;
     if (type == 0u) {
         const float4 *tp = sc.tris + (size_t)min(idx, sc.n_tris) * kTriVec;
-        float4 r0 = tp[0], r1 = tp[1], r2 = tp[2], r3 = tp[3];
-        n = V(r1.w, r2.w, r3.x);
-        mat = f2u(r0.w);
+        float4 r3 = tp[3];
+        n = V(r3.x, r3.y, r3.z);
+        mat = f2u(r3.w);
         if (dot(D, n) > 0.0f) n = -n;
     } else if (type == 1u) {
         const float4 *spn = sc.spheres + (size_t)min(idx, sc.n_spheres) * kSphereVec;
@@ -791,7 +715,7 @@ __device__ __forceinline__ bool bounce(const DevScene &sc, Path &ps, float tb, u
         thit = tp;
     }
     if (!exists) return false;
-    if (STATS && !RT_LANE_PROFILE) st.hits++;
+    if (STATS) st.hits++;
     const float4 *mp = sc.mats + (size_t)min(mat, sc.n_mats) * kMatVec;
     float4 q0 = mp[0], q1 = mp[1], q2 = mp[2], q3 = mp[3];
     float smooth = q0.w, trans = q1.w, f0 = q2.w, ior = q3.x, a2 = q3.y;
@@ -943,7 +867,6 @@ __device__ __forceinline__ bool tile_pixel(const TraceParams &p, bool sharded, i
 __device__ __forceinline__ bool trace_pixel(const TraceParams &p, bool sharded, int &x, int &y) {
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u;
     uint32_t tx, ty, wave;
-#if RT_XCD_MAP == 2
     static_assert((RT_MACRO * RT_MACRO * 4) % RT_TRACE_WAVES == 0, "a workgroup must not straddle macro tiles");
     const uint32_t mxn = (p.tiles_x + RT_MACRO - 1) / RT_MACRO, myn = (p.tiles_y + RT_MACRO - 1) / RT_MACRO;
     // j: index of this wavefront among those of its XCD
@@ -955,20 +878,6 @@ __device__ __forceinline__ bool trace_pixel(const TraceParams &p, bool sharded, 
     tx = (macro % mxn) * RT_MACRO + (t % RT_MACRO);
     ty = (macro / mxn) * RT_MACRO + (t / RT_MACRO);
     if (tx >= p.tiles_x || ty >= p.tiles_y) return false;
-#elif RT_XCD_MAP == 1
-    static_assert(RT_TRACE_WAVES == 1, "mapping 1 is written for one-wavefront workgroups");
-    const uint32_t per = (p.ntiles + 7u) / 8u, j = b >> 3;
-    const uint32_t tile = (b & 7u) * per + (j >> 2);
-    if (tile >= p.ntiles) return false;
-    wave = j & 3u;
-    tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-#else
-    static_assert(RT_TRACE_WAVES == 1, "mapping 0 is written for one-wavefront workgroups");
-    const uint32_t tile = b >> 2;
-    if (tile >= p.ntiles) return false;
-    wave = b & 3u;
-    tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-#endif
     x = (int)(tx * 16u + (wave & 1u) * 8u + (lane & 7u));
     y = (int)(ty * 16u + (wave >> 1) * 8u + (lane >> 3));
     bool live = (x < p.WW) && (y < p.HH);
@@ -1015,9 +924,9 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
         lds_top[node * RT_TOP_STRIDE + part] = sc.nodes[(size_t)min(node, sc.n_nodes) * kNodeVec + part];
     }
     __syncthreads();
-    const float4 *top = lds_top;
+    LdsTop top = (LdsTop)lds_top;
 #else
-    const float4 *top = nullptr;
+    LdsTop top = nullptr;
 #endif
     int x, y;
     bool live = trace_pixel(p, MODE == 1, x, y);
@@ -1025,75 +934,19 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
     uint32_t *stack = lds_stack + threadIdx.x;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0;
-    uint32_t warm_sink = 0u;  // keeps the cache-warming loads alive; word 28 of a node record is padding, always zero
     if (live) {
         Path ps;
         primary_ray(sc, p.W, p.H, x, y, p.time, ps);
         const uint32_t nb = (uint32_t)p.bounces;
         uint32_t aux0 = 0xFFFFFFFFu, aux1 = 0u, aux2 = 0u;
         for (uint32_t i = 0; i < nb; i++) {
-#if RT_LANE_PROFILE
-            if (STATS && first_active_lane()) st.overflow++;
-#endif
             v3 ID = V(1.0f / ps.D.x, 1.0f / ps.D.y, 1.0f / ps.D.z);
             float best = 1e38f;
             uint32_t code = 0xFFFFFFFFu;
             int sp = 1;
             stack[0] = 0u;
-#if RT_PREFETCH
-            // the next node's loads are issued before the pending leaves are intersected, so the two
-            // memory latencies of an iteration overlap instead of adding up
-            NodeRegs nd;
-            node_fetch<STATS, RT_TRACE_BLOCK, RT_STACK_LDS>(sc, sp, stack, spill, nd, st);
-            for (;;) {
-                LeafList ll;
-                node_test<STATS, RT_TRACE_BLOCK, RT_STACK_LDS>(sc, nd, ps.O, ID, best, sp, stack, spill, ll, st);
-                bool more = sp > 0;
-                if (more) node_fetch<STATS, RT_TRACE_BLOCK, RT_STACK_LDS>(sc, sp, stack, spill, nd, st);
-                while (ll.n > 0) leaf_one<STATS>(sc, ps.O, ps.D, best, code, ll, st);
-                if (!more) break;
-            }
-#elif RT_REGTOP
-            // the node to visit next lives in a register whenever the previous visit pushed one;
-            // the stack (sp entries) holds the rest.  sp + have = the reference's stackPtr.
-            uint32_t cur = 0u;
-            bool have = true;
-            sp = 0;
-            for (;;) {
-                if (STATS) {
-                    st.max_sp = max(st.max_sp, (uint32_t)sp + (have ? 1u : 0u));
-                    st.nodes++;
-                }
-                if (!have) cur = stack_pop<RT_TRACE_BLOCK, RT_STACK_LDS>(sp, stack, spill);
-                NodeRegs nd;
-                node_load(sc, cur, nd);
-                LeafList ll;
-                node_test<STATS, RT_TRACE_BLOCK, RT_STACK_LDS, true>(sc, nd, ps.O, ID, best, sp, stack, spill, ll, st, &cur,
-                                                               &have);
-#if RT_WARM
-                // Nothing touches the stack until the next visit, so the pop can be done now; one
-                // dword of the next node is then requested before the pending leaves are
-                // intersected.  It costs one register, and the node's cache line is on its way
-                // (or in L1) by the time the next visit loads it, instead of that latency being
-                // paid after the leaves'.
-                if (!have && sp > 0) {
-                    cur = stack_pop<RT_TRACE_BLOCK, RT_STACK_LDS>(sp, stack, spill);
-                    have = true;
-                }
-                uint32_t warm = 0u;
-                if (have) warm = reinterpret_cast<const uint32_t *>(sc.nodes + (size_t)min(cur, sc.n_nodes) * kNodeVec)[28];
-                while (ll.n > 0) leaf_one<STATS>(sc, ps.O, ps.D, best, code, ll, st);
-                warm_sink ^= warm;
-                if (!have) break;
-#else
-                while (ll.n > 0) leaf_one<STATS>(sc, ps.O, ps.D, best, code, ll, st);
-                if (!have && sp == 0) break;
-#endif
-            }
-#else
             while (sp > 0)
                 node_step<STATS, RT_TRACE_BLOCK, RT_STACK_LDS, RT_LDS_TOP>(sc, ps.O, ps.D, ID, best, code, sp, stack, spill, st, top);
-#endif
             nrays++;
             bool exists;
             float thit;
@@ -1112,20 +965,14 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
             write_aux_tail(p.aux, pix, ps, nrays);
         }
     }
-    flush_counters<STATS>(p.counters, lane, nrays + warm_sink, st);
+    flush_counters<STATS>(p.counters, lane, nrays, st);
 }
 
 void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s) {
     if (p.ntiles == 0) return;  // image smaller than one dispatch group: the reference dispatches nothing
     // 8 equal runs of workgroups, one per XCD; surplus workgroups exit at once
-#if RT_XCD_MAP == 2
     const uint32_t mx = (p.tiles_x + RT_MACRO - 1) / RT_MACRO, my = (p.tiles_y + RT_MACRO - 1) / RT_MACRO;
     const uint32_t groups = ((mx * my + 7u) / 8u) * 8u * (RT_MACRO * RT_MACRO * 4u) / RT_TRACE_WAVES;
-#elif RT_XCD_MAP == 1
-    const uint32_t groups = ((p.ntiles + 7u) / 8u) * 8u * 4u;
-#else
-    const uint32_t groups = p.ntiles * 4u;
-#endif
     dim3 grid(groups), block(RT_TRACE_BLOCK);
 #define L(M, A, S) hipLaunchKernelGGL((trace_kernel<M, A, S>), grid, block, 0, s, p)
     if (mode == 0) {
@@ -1187,28 +1034,46 @@ __global__ __launch_bounds__(RT_BLOCK) void generate_kernel(TraceParams p, WaveQ
     }
 }
 
-// Persistent traversal kernel.  Each wavefront owns the 64-slot chunks c = w, w + W, w + 2W, ...
-// of the queue (W = wavefronts launched): a static interleaved partition, so nothing is claimed
-// through memory.  Lanes whose stack is empty retire their result and are refilled in batches;
-// every lane with work performs one node step per iteration.  Terminates when the wavefront's
-// chunks are used up and every lane is idle.
+// Persistent traversal kernel.  Workgroups of four independent wavefronts (one-wavefront
+// workgroups cannot fill a CU: at most 8 workgroups are resident per CU, i.e. 2 waves per SIMD).
+// The queue is cut in 8 equal regions, one per XCD (the tiles whose rays a region holds were
+// generated by workgroups of the same XCD under round-robin placement, so their nodes are in that
+// XCD's L2); within its XCD's region wavefront w of the Wx resident there owns the 64-slot chunks
+// w, w + Wx, w + 2 Wx, ...: a static interleaved partition, so nothing is claimed through memory.
+// Lanes whose stack is empty retire their result and are refilled in batches; every lane with
+// work performs one node step per iteration.  A wavefront ends when its chunks are used up and
+// every lane is idle.  The workgroup shares one LDS copy of the top of the tree.
 template <bool STATS>
-__global__ __launch_bounds__(64, RT_EXTEND_MIN_WAVES) void extend_kernel(DevScene sc, WaveQueues q, uint32_t n_slots,
-                                                                        uint32_t refill_threshold,
-                                                                        uint32_t leaf_threshold, Counters *counters,
-                                                                        uint32_t *aux) {
-    __shared__ uint32_t lds_stack[RT_EXT_STACK_LDS * 64];
+__global__ __launch_bounds__(RT_BLOCK, RT_EXTEND_MIN_WAVES) void extend_kernel(DevScene sc, WaveQueues q, uint32_t n_slots,
+                                                                              uint32_t refill_threshold,
+                                                                              uint32_t leaf_threshold, Counters *counters,
+                                                                              uint32_t *aux) {
+    __shared__ uint32_t lds_stack[RT_EXT_STACK_LDS * RT_BLOCK];
     uint32_t spill[RT_STACK_SPILL];
-    const uint32_t lane = threadIdx.x;
-    uint32_t *stack = lds_stack + lane;
+#if RT_LDS_TOP > 0
+    __shared__ float4 lds_top[RT_LDS_TOP * RT_TOP_STRIDE];
+    for (uint32_t k = threadIdx.x; k < RT_LDS_TOP * 7u; k += RT_BLOCK) {
+        const uint32_t node = k / 7u, part = k % 7u;
+        lds_top[node * RT_TOP_STRIDE + part] = sc.nodes[(size_t)min(node, sc.n_nodes) * kNodeVec + part];
+    }
+    __syncthreads();  // the only barrier: the wavefronts are independent from here on
+    LdsTop top = (LdsTop)lds_top;
+#else
+    LdsTop top = nullptr;
+#endif
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *stack = lds_stack + wave * (RT_EXT_STACK_LDS * 64u) + lane;
     const float4 *__restrict__ rays = q.rays[0];
     float2 *__restrict__ hits = q.hits;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nrays_done = 0;
     // wave-uniform cursor over this wavefront's chunks
-    uint32_t chunk = blockIdx.x;
+    const uint32_t n_chunks = (n_slots + 63u) / 64u, per_xcd = (n_chunks + 7u) / 8u;
+    const uint32_t xcd = blockIdx.x & 7u, waves_x = (gridDim.x >> 3) * (RT_BLOCK / 64u);
+    const uint32_t region_end = min((xcd + 1u) * per_xcd, n_chunks);
+    uint32_t chunk = xcd * per_xcd + (blockIdx.x >> 3) * (RT_BLOCK / 64u) + wave;
     uint32_t cur = chunk * 64u, end = min(cur + 64u, n_slots);
-    bool exhausted = cur >= n_slots;
+    bool exhausted = chunk >= region_end;
     int ray = -1;
     int sp = 0;
     v3 O = V(0, 0, 0), D = V(0, 0, 0), ID = V(0, 0, 0);
@@ -1254,10 +1119,10 @@ __global__ __launch_bounds__(64, RT_EXTEND_MIN_WAVES) void extend_kernel(DevScen
                     cur += take;
                     given += take;
                     if (cur >= end) {
-                        chunk += gridDim.x;
+                        chunk += waves_x;
                         cur = chunk * 64u;
                         end = min(cur + 64u, n_slots);
-                        if (chunk >= (n_slots + 63u) / 64u) exhausted = true;
+                        if (chunk >= region_end) exhausted = true;
                     }
                 }
             }
@@ -1274,7 +1139,7 @@ __global__ __launch_bounds__(64, RT_EXTEND_MIN_WAVES) void extend_kernel(DevScen
             if (pending) leaf_one<STATS>(sc, O, D, best, code, ll, st);
         } else if (node_ready) {
             if (STATS) nodes_this_ray++;
-            node_part<STATS, 64, RT_EXT_STACK_LDS>(sc, O, ID, best, sp, stack, spill, ll, st);
+            node_part<STATS, 64, RT_EXT_STACK_LDS, RT_LDS_TOP>(sc, O, ID, best, sp, stack, spill, ll, st, top);
         }
     }
     flush_counters<STATS>(counters, lane, nrays_done, st);
@@ -1345,14 +1210,16 @@ void launch_wavefront_frame(const TraceParams &p, const WaveQueues &q, int mode,
         G(1, false);
     }
 #undef G
+    // workgroups of four wavefronts in a multiple of 8 (one share per XCD), no more wavefronts than chunks
     const uint32_t n_chunks = n_slots / 64u;
-    const uint32_t ewaves = extend_waves < n_chunks ? extend_waves : n_chunks;
+    uint32_t egroups = ((extend_waves < n_chunks ? extend_waves : n_chunks) / (RT_BLOCK / 64u) + 7u) / 8u * 8u;
+    if (egroups < 8u) egroups = 8u;
     for (uint32_t b = 0; b < nb; b++) {
         if (stats)
-            hipLaunchKernelGGL((extend_kernel<true>), dim3(ewaves), dim3(64), 0, s, p.scene, q, n_slots,
+            hipLaunchKernelGGL((extend_kernel<true>), dim3(egroups), dim3(RT_BLOCK), 0, s, p.scene, q, n_slots,
                                refill_threshold, leaf_threshold, p.counters, aux ? p.aux : nullptr);
         else
-            hipLaunchKernelGGL((extend_kernel<false>), dim3(ewaves), dim3(64), 0, s, p.scene, q, n_slots,
+            hipLaunchKernelGGL((extend_kernel<false>), dim3(egroups), dim3(RT_BLOCK), 0, s, p.scene, q, n_slots,
                                refill_threshold, leaf_threshold, p.counters, (uint32_t *)nullptr);
 #define S(M, A, T) hipLaunchKernelGGL((shade_kernel<M, A, T>), tgrid, block, 0, s, p, q, n_slots, b)
         if (mode == 0) {

@@ -13,7 +13,7 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int PACKED>
-__global__ __launch_bounds__(64) void stream_kernel(float *out, int iters, long long *cycles) {
+__global__ __launch_bounds__(256) void stream_kernel(float *out, int iters, long long *cycles) {
     float a0 = threadIdx.x * 0.001f + 1.0f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,
           a6 = a0 + 6, a7 = a0 + 7;
     float m = 1.0000001f;
@@ -40,10 +40,11 @@ __global__ __launch_bounds__(64) void stream_kernel(float *out, int iters, long 
     long long t1 = __builtin_readcyclecounter();
     long long r1 = __builtin_amdgcn_s_memrealtime();
     float r = PACKED ? (p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y) : (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
-    out[blockIdx.x * 64 + threadIdx.x] = r;
-    if (threadIdx.x == 0) {
-        cycles[2 * blockIdx.x] = t1 - t0;
-        cycles[2 * blockIdx.x + 1] = r1 - r0;
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) {
+        const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+        cycles[2 * w] = t1 - t0;
+        cycles[2 * w + 1] = r1 - r0;
     }
 }
 
@@ -55,7 +56,7 @@ int main() {
     const int cus = prop.multiProcessorCount;
     float *out;
     long long *cyc;
-    const int max_blocks = cus * 4 * 8;
+    const int max_blocks = cus * 4 * 8;  // in wavefronts
     CHECK(hipMalloc(&out, sizeof(float) * 64 * max_blocks));
     CHECK(hipMalloc(&cyc, sizeof(long long) * 2 * max_blocks));
     std::vector<long long> hc(2 * (size_t)max_blocks);
@@ -63,14 +64,17 @@ int main() {
     printf("CUs %d, clock %d kHz\n", cus, prop.clockRate);
     for (int packed = 0; packed < 2; packed++) {
         for (int wps = 1; wps <= 8; wps *= 2) {
-            int blocks = cus * 4 * wps;  // one-wave blocks; the dispatcher spreads them over the SIMDs
+            // workgroups of four wavefronts (one per SIMD), wps of them per CU.  One-wavefront workgroups
+            // would not do: at most 8 workgroups are resident per CU, so they never exceed 2 waves per SIMD.
+            int blocks = cus * 4 * wps;  // wavefronts launched
+            const int groups = cus * wps;
             hipEvent_t e0, e1;
             CHECK(hipEventCreate(&e0));
             CHECK(hipEventCreate(&e1));
             for (int rep = 0; rep < 2; rep++) {
                 CHECK(hipEventRecord(e0));
-                if (packed) hipLaunchKernelGGL(stream_kernel<1>, dim3(blocks), dim3(64), 0, 0, out, iters, cyc);
-                else hipLaunchKernelGGL(stream_kernel<0>, dim3(blocks), dim3(64), 0, 0, out, iters, cyc);
+                if (packed) hipLaunchKernelGGL(stream_kernel<1>, dim3(groups), dim3(256), 0, 0, out, iters, cyc);
+                else hipLaunchKernelGGL(stream_kernel<0>, dim3(groups), dim3(256), 0, 0, out, iters, cyc);
                 CHECK(hipEventRecord(e1));
                 CHECK(hipEventSynchronize(e1));
             }
