@@ -207,6 +207,37 @@ def run_c4(args, r, comm, rank, world, name, bufs, build_s, rehearse):
     kernel_ms = float(np.mean(ev_ms))
     rays_per_launch = r.stats()["rays"] / len(ev_ms)
 
+    # the opt-in fast mode (own tree, free traversal order: NOT the reference's algorithm, never the
+    # headline) on the same workload, reported separately
+    fast = None
+    if world == 1:
+        r.fast_mode = True
+        try:
+            r.set_flags(stats=True)
+            r.reset_stats()
+            r.set_frame_index(0)
+            r.render()
+            r.sync()
+            fs = r.stats()
+            r.set_flags()
+            f_elapsed, f_rays = timed_loop(frame_step)
+            r.reset_stats()
+            f_ev = []
+            for i in range(min(args.steps, 10)):
+                r.render_sum(first_frame=i, nframes=1)
+                r.sync()
+                f_ev.append(r.stats()["last_trace_ms"])
+            fast = {"value": f_rays / f_elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": f_elapsed / args.steps * 1e3,
+                    "kernel_ms": float(np.mean(f_ev)),
+                    "node_visits_per_ray": fs["nodes"] / max(1, fs["rays"]),
+                    "triangle_tests_per_ray": fs["tri_tests"] / max(1, fs["rays"]),
+                    "what": "opt-in, default off, not the reference's data: the library's own tree (all-axis SAH, "
+                            "conservative 8-bit child boxes, 64-byte nodes) under the same traversal rules; same step as "
+                            "the headline (rt_render). Results differ from the reference where its tree decides which "
+                            "hit is found (tests/test_gpu_fast_mode.py counts them)"}
+        finally:
+            r.fast_mode = False
+
     tmax = comm.all_reduce([elapsed, sum_elapsed], "max")
     tsum = comm.all_reduce([rays, sum_rays], "sum")
     if rank != 0:
@@ -231,6 +262,8 @@ def run_c4(args, r, comm, rank, world, name, bufs, build_s, rehearse):
                              "pass): the per-GPU step of the multi-GPU runs, comparable across n_gpus"},
         "roofline": roofline_block(name, args, kernel_ms, rays_per_launch, per_ray),
     }
+    if world == 1:
+        out["fast_mode"] = fast
     if not args.no_cpu_baseline and world == 1:
         threads = min(16, os.cpu_count() or 1)
         out["cpu_baseline"] = cpu_baseline(bufs, Camera().uniforms_f32(), args.width, args.height, args.bounces,

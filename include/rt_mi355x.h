@@ -142,6 +142,24 @@ int rt_clear_sum(rt_ctx *ctx, float *sum_rgba);
 int rt_finalize_sum(rt_ctx *ctx, const float *sum_rgba, uint32_t spp);
 
 /*
+ * Fast mode: opt-in, default off, NOT the reference's data and never what parity is claimed for.
+ * The reference's tree (src/bvh/bvh_node.py:103-230: SAH on the axis depth % 3; :476-480: child
+ * boxes rounded to the nearest 16-bit code, so not conservative) decides which hits a ray finds;
+ * the default mode consumes exactly that tree (binding 11).  With fast mode on, rt_render /
+ * rt_render_sum traverse the library's own tree instead -- all-axis SAH, conservative 8-bit child
+ * boxes in 64-byte nodes -- built on the host from the uploaded triangles, spheres and boxes
+ * (binding 11 is ignored).  The traversal rules (compute.glsl:225-330), ray generation,
+ * intersection routines, materials and RNG are unchanged, so images differ from the default mode
+ * only where the reference's tree decides the hit.  The wavefront pipeline (RT_PIPELINE=wave)
+ * does not apply to it.  rt_fast_bvh_size / rt_fast_bvh_export hand out the built tree (64-byte
+ * node records, layout in csrc/rt_fastbvh.cpp; the export holds n_nodes + 1 of them, the last an
+ * all-empty sentinel) so that a checker can traverse exactly the same data.
+ */
+int rt_set_fast_mode(rt_ctx *ctx, int enable);
+int rt_fast_bvh_size(rt_ctx *ctx, uint32_t *n_nodes);
+int rt_fast_bvh_export(rt_ctx *ctx, void *nodes, size_t nodes_bytes);
+
+/*
  * Collectives for multi-GPU runs: one process per GPU, RCCL over xGMI, no framework needed (no
  * counterpart in the reference).  Rank 0 draws an id with rt_comm_unique_id and hands its
  * RT_COMM_ID_BYTES bytes to the other ranks by any means (a file, an environment variable, a

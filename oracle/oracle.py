@@ -115,6 +115,26 @@ class OracleScene:
         return out[0] if len(out) == 1 else tuple(out)
 
 
+def set_fast_bvh(nodes=None):
+    """Switches the oracle to the fast-mode tree (the (n + 1, 16) array from
+    raytracer_amd.scene.build_fast_bvh or Renderer.fast_bvh, sentinel included), or back to the
+    reference's tree with None.  The array is kept alive here while set."""
+    global _FAST_KEEP
+    L = lib()
+    L.rto_set_fast_bvh.restype = None
+    L.rto_set_fast_bvh.argtypes = [C.c_void_p, C.c_uint32]
+    if nodes is None:
+        L.rto_set_fast_bvh(None, 0)
+        _FAST_KEEP = None
+        return
+    n = np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1, 16)
+    _FAST_KEEP = n
+    L.rto_set_fast_bvh(n.ctypes.data, n.shape[0] - 1)
+
+
+_FAST_KEEP = None
+
+
 def _render_window(self, w, h, x0, y0, ww, wh, frame, bounces, threads=0):
     """Pixels [x0, x0+ww) x [y0, y0+wh) of the w x h frame, as a dense (wh, ww, 4) image."""
     img = np.zeros((wh, ww, 4), dtype=np.float32)

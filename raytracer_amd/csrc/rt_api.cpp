@@ -5,6 +5,7 @@
 #include "../../include/rt_mi355x.h"
 #include "rt_internal.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -111,6 +112,13 @@ struct rt_ctx {
     int pipeline = 0;
     rt::WaveQueues q = {{nullptr, nullptr}, nullptr, nullptr};
     uint64_t pixel_samples = 0;  // pixel-samples queued since the last rt_reset_stats
+    // fast mode (opt-in; rt_set_fast_mode): the library's own tree, built on the host from copies
+    // of the uploaded triangles, spheres and boxes
+    bool fast = false, fast_dirty = true;
+    std::vector<uint32_t> host_tris, host_spheres, host_boxes;
+    rt::FastBvh fbvh;
+    float4 *fnodes = nullptr;
+    size_t fnodes_cap = 0;  // bytes
     void *comm = nullptr;  // RCCL communicator (rt_comm_init)
     int comm_rank = 0, comm_world = 1;
     double *comm_scratch = nullptr;
@@ -199,7 +207,9 @@ int alloc_images(rt_ctx *c, int width, int height) {
 
 // one frame on stream `s` with the selected pipeline
 void trace_frame(rt_ctx *c, const rt::TraceParams &p, int mode, bool aux, bool stats, hipStream_t s) {
-    if (c->pipeline == 0)
+    if (c->fast)
+        rt::launch_trace_fast(p, mode, aux, stats, s);
+    else if (c->pipeline == 0)
         rt::launch_trace(p, mode, aux, stats, s);
     else
         rt::launch_wavefront_frame(p, c->q, mode, aux, stats, c->extend_waves, c->refill_threshold, c->leaf_threshold, s);
@@ -295,6 +305,26 @@ int repack(rt_ctx *c, int binding) {
     return 0;
 }
 
+// builds the fast-mode tree if the primitives changed since the last build and copies it to the device
+int prepare_fast(rt_ctx *c) {
+    if (!c->fast_dirty) return 0;
+    if (int rc = sync_all(c)) return rc;  // frames in flight still read the old tree
+    c->main_dirty = true;
+    rt::build_fast_bvh(c->host_tris.data(), (uint32_t)(c->host_tris.size() / 16), c->host_spheres.data(),
+                       (uint32_t)(c->host_spheres.size() / 8), c->host_boxes.data(), (uint32_t)(c->host_boxes.size() / 8),
+                       c->fbvh);
+    const size_t nb = c->fbvh.nodes.size() * 4;
+    if (nb > c->fnodes_cap) {
+        if (c->fnodes) HIP_TRY(hipFree(c->fnodes));
+        c->fnodes = nullptr, c->fnodes_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->fnodes, nb));
+        c->fnodes_cap = nb;
+    }
+    HIP_TRY(hipMemcpy(c->fnodes, c->fbvh.nodes.data(), nb, hipMemcpyHostToDevice));
+    c->fast_dirty = false;
+    return 0;
+}
+
 int prepare_scene(rt_ctx *c, rt::DevScene *s) {
     for (int binding : {RT_BINDING_SPHERES, RT_BINDING_PLANES, RT_BINDING_BOXES, RT_BINDING_MATERIALS,
                         RT_BINDING_BVH, RT_BINDING_TRIANGLES})
@@ -311,6 +341,13 @@ int prepare_scene(rt_ctx *c, rt::DevScene *s) {
     s->n_boxes = c->boxes.count;
     s->n_planes = c->planes.count;
     s->n_mats = c->mats.count;
+    s->fnodes = nullptr;
+    s->n_fnodes = 0;
+    if (c->fast) {
+        if (int rc = prepare_fast(c)) return rc;
+        s->fnodes = c->fnodes;
+        s->n_fnodes = c->fbvh.n_nodes;
+    }
     memcpy(s->inv_vp, c->inv_vp, sizeof s->inv_vp);
     memcpy(s->eye, c->eye, sizeof s->eye);
     memcpy(s->smin, c->smin, sizeof s->smin);
@@ -473,6 +510,7 @@ int rt_destroy(rt_ctx *c) {
         if (b->raw) (void)hipFree(b->raw);
         if (b->packed) (void)hipFree(b->packed);
     }
+    if (c->fnodes) (void)hipFree(c->fnodes);
     for (void *p : {(void *)c->node_order, (void *)c->node_rank, (void *)c->sample, (void *)c->sample2, (void *)c->acc,
                     (void *)c->sum, (void *)c->sum2, (void *)c->aux, (void *)c->counters, (void *)c->q.rays[0],
                     (void *)c->q.hits, (void *)c->q.paths})
@@ -516,6 +554,12 @@ int rt_upload(rt_ctx *c, int binding, const void *data, size_t nbytes) {
         HIP_TRY(hipMemcpy(b->raw, data, nbytes, hipMemcpyHostToDevice));
     }
     if (binding == RT_BINDING_BVH) c->host_nodes.assign((const uint32_t *)data, (const uint32_t *)data + nbytes / 4);
+    if (binding == RT_BINDING_TRIANGLES || binding == RT_BINDING_SPHERES || binding == RT_BINDING_BOXES) {
+        std::vector<uint32_t> &h = binding == RT_BINDING_TRIANGLES ? c->host_tris
+                                   : binding == RT_BINDING_SPHERES ? c->host_spheres : c->host_boxes;
+        h.assign((const uint32_t *)data, (const uint32_t *)data + nbytes / 4);
+        c->fast_dirty = true;
+    }
     b->dirty = true;
     return 0;
 }
@@ -721,6 +765,33 @@ int rt_render_sum(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounc
     }
     HIP_TRY(hipGetLastError());
     return end_timed(c);
+}
+
+int rt_set_fast_mode(rt_ctx *c, int enable) {
+    if (!c) return fail("rt_set_fast_mode: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if ((enable != 0) != c->fast)
+        if (int rc = sync_all(c)) return rc;
+    c->fast = enable != 0;
+    return 0;
+}
+
+int rt_fast_bvh_size(rt_ctx *c, uint32_t *n_nodes) {
+    if (!c || !n_nodes) return fail("rt_fast_bvh_size: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = prepare_fast(c)) return rc;
+    *n_nodes = c->fbvh.n_nodes;
+    return 0;
+}
+
+int rt_fast_bvh_export(rt_ctx *c, void *nodes, size_t nodes_bytes) {
+    if (!c || !nodes) return fail("rt_fast_bvh_export: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = prepare_fast(c)) return rc;
+    if (nodes_bytes != c->fbvh.nodes.size() * 4)
+        return fail("rt_fast_bvh_export: the buffer must hold 64 bytes times (the count rt_fast_bvh_size reports + 1)");
+    memcpy(nodes, c->fbvh.nodes.data(), nodes_bytes);
+    return 0;
 }
 
 int rt_sum_buffer(rt_ctx *c, float **device_ptr, size_t *nbytes) {

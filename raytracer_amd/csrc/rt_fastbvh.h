@@ -1,0 +1,18 @@
+// Host-side builder of the fast-mode tree (no GPU dependency: also built into librt_scene.so).
+#pragma once
+
+#include <stdint.h>
+
+#include <vector>
+
+namespace rt {
+
+struct FastBvh {
+    std::vector<uint32_t> nodes;  // 16 words per node: n_nodes nodes plus one all-empty sentinel
+    uint32_t n_nodes = 0;
+};
+// builds the tree from host copies of the uploaded reference-layout buffers (record layouts: rt_fastbvh.cpp)
+void build_fast_bvh(const uint32_t *tris, uint32_t n_tris, const uint32_t *spheres, uint32_t n_spheres,
+                    const uint32_t *boxes, uint32_t n_boxes, FastBvh &out);
+
+}  // namespace rt

@@ -5,6 +5,9 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
+
+#include "rt_fastbvh.h"
 
 struct rt_ctx;
 
@@ -37,6 +40,9 @@ struct DevScene {
     // element counts; every repacked array carries one extra all-zero-source element at index n,
     // which is what an out-of-range index reads (GL robust buffer access returns zeros)
     uint32_t n_nodes, n_tris, n_spheres, n_boxes, n_planes, n_mats;
+    // fast mode only (rt_fastbvh.cpp): the library's own tree, 4 x float4 per node, n_fnodes nodes + a sentinel
+    const float4 *fnodes;
+    uint32_t n_fnodes;
     float inv_vp[16];
     float eye[3];
     float smin[3], sext[3];  // scene_min / scene_extent uniforms (child boxes are decoded with them)
@@ -71,6 +77,10 @@ struct WaveQueues {
     float2 *hits;     // per slot: distance, primitive metadata word
     float4 *paths;    // per slot: 2 x float4 (throughput+rng, light+ior)
 };
+
+// ---- fast mode: the library's own acceleration structure (rt_fastbvh.h / rt_fastbvh.cpp) -----
+// one frame with the fast-mode traversal (same modes and flags as launch_trace)
+void launch_trace_fast(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s);
 
 // repack kernels: reference byte layouts -> device records (n elements + 1 zero-source sentinel)
 void launch_repack_nodes(const uint32_t *src, uint32_t n, const float smin[3], const float sext[3],

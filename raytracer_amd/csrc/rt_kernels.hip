@@ -38,6 +38,9 @@ namespace rt {
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 8  // megakernel: waves per SIMD the register allocator must leave room for
 #endif
+#ifndef RT_FAST_TOP
+#define RT_FAST_TOP 192    // fast mode: leading nodes (64 bytes each) kept in LDS per workgroup: 12 KB
+#endif
 #ifndef RT_MACRO
 #define RT_MACRO 2    // megakernel tile placement: macro tile = RT_MACRO x RT_MACRO tiles of 16x16 pixels, dealt to the XCDs in turn
 #endif
@@ -156,6 +159,9 @@ __device__ __forceinline__ float l2s(float c) {
     if (c <= 0.0031308f) return 12.92f * c;
     return (1.0f + 0.055f) * d_pow(c, 1.0f / 2.4f) - 0.055f;
 }
+
+// fast mode only: reciprocal of a direction component, kept finite
+__device__ __forceinline__ float fast_rcp(float d) { return fabsf(d) > 1e-20f ? 1.0f / d : copysignf(1e20f, d); }
 
 // compute.glsl:749-760
 __device__ __forceinline__ float draw(uint32_t &s) {
@@ -413,8 +419,22 @@ __device__ __forceinline__ float4 ld4(GlobalNodes p) {
 // Issues the loads of node ni.  TOP > 0: the first TOP nodes (breadth-first numbering, i.e. the top
 // levels of the tree) are read from the workgroup's LDS copy `top` instead of through the vector
 // memory pipeline, which is what bounds this kernel.
-template <int TOP = 0>
+// FAST (the opt-in fast mode, not the reference's data): the node is one of the library's own
+// 64-byte records (rt_fastbvh.cpp), 4 x 16 bytes: n0 = origin.xyz + exponents, n1 = lo_x hi_x lo_y
+// hi_y codes, n2 = lo_z hi_z codes, n3 = child words; they travel in lox, hix, loy and mt.
+template <int TOP = 0, bool FAST = false>
 __device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeRegs &nd, LdsTop top = nullptr) {
+    if (FAST) {
+        ni = min(ni, sc.n_fnodes);  // out-of-range -> the all-empty sentinel node
+        if (TOP > 0 && ni < (uint32_t)TOP) {
+            LdsTop tp = top + ni * 4u;
+            nd.lox = ld4(tp), nd.hix = ld4(tp + 1), nd.loy = ld4(tp + 2), nd.mt = ld4(tp + 3);
+            return;
+        }
+        GlobalNodes np = (GlobalNodes)sc.fnodes + (size_t)ni * 4u;
+        nd.lox = ld4(np), nd.hix = ld4(np + 1), nd.loy = ld4(np + 2), nd.mt = ld4(np + 3);
+        return;
+    }
     ni = min(ni, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
     if (TOP > 0 && ni < (uint32_t)TOP) {
         LdsTop tp = top + ni * RT_TOP_STRIDE;
@@ -440,24 +460,46 @@ __device__ __forceinline__ uint32_t stack_pop(int &sp, const uint32_t *stack, co
 }
 
 // Pops the next node index and issues its loads.
-template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP = 0>
+template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP = 0, bool FAST = false>
 __device__ __forceinline__ void node_fetch(const DevScene &sc, int &sp, const uint32_t *stack, const uint32_t *spill,
                                            NodeRegs &nd, LaneStats &st, LdsTop top = nullptr) {
     if (STATS) {
         st.max_sp = max(st.max_sp, (uint32_t)sp);
         st.nodes++;
     }
-    node_load<TOP>(sc, stack_pop<STRIDE, LDS_DEPTH>(sp, stack, spill), nd, top);
+    node_load<TOP, FAST>(sc, stack_pop<STRIDE, LDS_DEPTH>(sp, stack, spill), nd, top);
 }
 
-// Slab tests, sort, pushes and leaf list for a fetched node.
-template <bool STATS, int STRIDE, int LDS_DEPTH>
+// Slab tests, sort, pushes and leaf list for a fetched node.  FAST: the child boxes come from 8-bit
+// codes, plane distance = fma(code, scale * ID, (origin - O) * ID) with ID kept finite by the
+// caller, the exit distance is widened by 4 ulp, and an empty child slot (0xFFFFFFFF) is never valid.
+template <bool STATS, int STRIDE, int LDS_DEPTH, bool FAST = false>
 __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd, v3 O, v3 ID, float best, int &sp,
                                           uint32_t *stack, uint32_t *spill, LeafList &ll, LaneStats &st) {
-    float4 lox = nd.lox, hix = nd.hix, loy = nd.loy, hiy = nd.hiy, loz = nd.loz, hiz = nd.hiz;
     uint32_t m0 = f2u(nd.mt.x), m1 = f2u(nd.mt.y), m2 = f2u(nd.mt.z), m3 = f2u(nd.mt.w);
     float k0, k1, k2, k3;
     uint32_t v0, v1, v2, v3_;  // 1 = the child is visited
+    if (FAST) {
+        const uint32_t ew = f2u(nd.lox.w);
+        const float ax = u2f((ew & 0xFFu) << 23) * ID.x, ay = u2f(((ew >> 8) & 0xFFu) << 23) * ID.y,
+                    az = u2f(((ew >> 16) & 0xFFu) << 23) * ID.z;
+        const float bx = (nd.lox.x - O.x) * ID.x, by = (nd.lox.y - O.y) * ID.y, bz = (nd.lox.z - O.z) * ID.z;
+        const uint32_t qlx = f2u(nd.hix.x), qhx = f2u(nd.hix.y), qly = f2u(nd.hix.z), qhy = f2u(nd.hix.w),
+                       qlz = f2u(nd.loy.x), qhz = f2u(nd.loy.y);
+#define FSLAB(SH, M, KEY, VAL)                                                                             \
+    {                                                                                                       \
+        float t1x = __builtin_fmaf((float)((qlx >> SH) & 0xFFu), ax, bx), t2x = __builtin_fmaf((float)((qhx >> SH) & 0xFFu), ax, bx); \
+        float t1y = __builtin_fmaf((float)((qly >> SH) & 0xFFu), ay, by), t2y = __builtin_fmaf((float)((qhy >> SH) & 0xFFu), ay, by); \
+        float t1z = __builtin_fmaf((float)((qlz >> SH) & 0xFFu), az, bz), t2z = __builtin_fmaf((float)((qhz >> SH) & 0xFFu), az, bz); \
+        float tN = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));            \
+        float tF = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z)) * 1.0000004f;            \
+        KEY = tN;                                                                                           \
+        VAL = ((tN <= tF) && (tN < best) && (M != 0xFFFFFFFFu)) ? 1u : 0u;                                  \
+    }
+        FSLAB(0, m0, k0, v0) FSLAB(8, m1, k1, v1) FSLAB(16, m2, k2, v2) FSLAB(24, m3, k3, v3_)
+#undef FSLAB
+    } else {
+    float4 lox = nd.lox, hix = nd.hix, loy = nd.loy, hiy = nd.hiy, loz = nd.loz, hiz = nd.hiz;
     // compute.glsl:186-208, one child per macro expansion
 #define SLAB(c, KEY, VAL)                                                                        \
     {                                                                                            \
@@ -471,6 +513,7 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
     }
     SLAB(x, k0, v0) SLAB(y, k1, v1) SLAB(z, k2, v2) SLAB(w, k3, v3_)
 #undef SLAB
+    }
     // compute.glsl:210-223
     CSWAP(k0, k1, m0, m1, v0, v1)
     CSWAP(k2, k3, m2, m3, v2, v3_)
@@ -534,12 +577,12 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
     ll.n = nl;
 }
 
-template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP = 0>
+template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP = 0, bool FAST = false>
 __device__ __forceinline__ void node_part(const DevScene &sc, v3 O, v3 ID, float best, int &sp, uint32_t *stack,
                                           uint32_t *spill, LeafList &ll, LaneStats &st, LdsTop top = nullptr) {
     NodeRegs nd;
-    node_fetch<STATS, STRIDE, LDS_DEPTH, TOP>(sc, sp, stack, spill, nd, st, top);
-    node_test<STATS, STRIDE, LDS_DEPTH>(sc, nd, O, ID, best, sp, stack, spill, ll, st);
+    node_fetch<STATS, STRIDE, LDS_DEPTH, TOP, FAST>(sc, sp, stack, spill, nd, st, top);
+    node_test<STATS, STRIDE, LDS_DEPTH, FAST>(sc, nd, O, ID, best, sp, stack, spill, ll, st);
 }
 
 // Intersects the first pending leaf of the list (compute.glsl:299-322).
@@ -575,12 +618,12 @@ __device__ __forceinline__ void leaf_one(const DevScene &sc, v3 O, v3 D, float &
 }
 
 // One iteration of the reference's `while (stackPtr > 0)` loop.
-template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP = 0>
+template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP = 0, bool FAST = false>
 __device__ __forceinline__ void node_step(const DevScene &sc, v3 O, v3 D, v3 ID, float &best, uint32_t &best_code,
                                           int &sp, uint32_t *stack, uint32_t *spill, LaneStats &st,
                                           LdsTop top = nullptr) {
     LeafList ll;
-    node_part<STATS, STRIDE, LDS_DEPTH, TOP>(sc, O, ID, best, sp, stack, spill, ll, st, top);
+    node_part<STATS, STRIDE, LDS_DEPTH, TOP, FAST>(sc, O, ID, best, sp, stack, spill, ll, st, top);
     while (ll.n > 0) leaf_one<STATS>(sc, O, D, best, best_code, ll, st);
 }
 
@@ -617,12 +660,14 @@ __device__ __forceinline__ void hit_attributes(const DevScene &sc, v3 O, v3 D, f
     }
 }
 
-// compute.glsl:767-805; the loop bound is inclusive, the extra record reads as zeros
+// compute.glsl:767-805.  The reference's loop bound is inclusive; the extra record reads as zeros
+// (robust buffer access), i.e. a plane with a zero normal: denom is +-0, the test -denom > 1e-7
+// fails, and the iteration changes nothing.  It is therefore left out.
 __device__ __forceinline__ void planes_nearest(const DevScene &sc, v3 O, v3 D, bool &exists, float &t_best, v3 &pos,
                                                v3 &n, uint32_t &mat) {
     exists = false;
     t_best = 9999999.0f;
-    for (uint32_t i = 0; i <= sc.n_planes; i++) {
+    for (uint32_t i = 0; i < sc.n_planes; i++) {
         float4 p0 = sc.planes[(size_t)i * 2], p1 = sc.planes[(size_t)i * 2 + 1];
         v3 pp = V(p0.x, p0.y, p0.z), pn = V(p1.x, p1.y, p1.z);
         float denom = dot(pn, D);
@@ -911,23 +956,29 @@ __device__ __forceinline__ void write_aux_tail(uint32_t *aux, size_t pix, const 
 // ------------------------------------------------------------------------------------------
 // pipeline A — megakernel: one lane = one pixel-sample, the whole of main() (compute.glsl:451-688)
 // ------------------------------------------------------------------------------------------
-template <int MODE, bool AUX, bool STATS>
+// FAST: the opt-in fast mode -- the same kernel over the library's own tree (rt_fastbvh.cpp): all-axis
+// SAH, conservative 8-bit child boxes in 64-byte nodes (4 x 16-byte requests per visit instead of
+// 7, and 192 of them fit the workgroup's LDS copy instead of 109).  NOT the reference's tree, so
+// results differ where the reference's boxes or visiting order decide which hit is found.
+template <int MODE, bool AUX, bool STATS, bool FAST = false>
 __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(TraceParams p) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_TRACE_BLOCK];
     uint32_t spill[RT_STACK_SPILL];
     const DevScene &sc = p.scene;
-#if RT_LDS_TOP > 0
+    constexpr int TOP = FAST ? RT_FAST_TOP : RT_LDS_TOP;
     // the workgroup's copy of the top of the tree (breadth-first numbering: the first records)
-    __shared__ float4 lds_top[RT_LDS_TOP * RT_TOP_STRIDE];
-    for (uint32_t k = threadIdx.x; k < RT_LDS_TOP * 7u; k += RT_TRACE_BLOCK) {
-        const uint32_t node = k / 7u, part = k % 7u;
-        lds_top[node * RT_TOP_STRIDE + part] = sc.nodes[(size_t)min(node, sc.n_nodes) * kNodeVec + part];
+    __shared__ float4 lds_top[RT_LDS_TOP * RT_TOP_STRIDE > RT_FAST_TOP * 4 ? RT_LDS_TOP * RT_TOP_STRIDE : RT_FAST_TOP * 4];
+    if (FAST) {
+        for (uint32_t k = threadIdx.x; k < RT_FAST_TOP * 4u; k += RT_TRACE_BLOCK)
+            lds_top[k] = sc.fnodes[(size_t)min(k >> 2, sc.n_fnodes) * 4u + (k & 3u)];
+    } else {
+        for (uint32_t k = threadIdx.x; k < RT_LDS_TOP * 7u; k += RT_TRACE_BLOCK) {
+            const uint32_t node = k / 7u, part = k % 7u;
+            lds_top[node * RT_TOP_STRIDE + part] = sc.nodes[(size_t)min(node, sc.n_nodes) * kNodeVec + part];
+        }
     }
     __syncthreads();
     LdsTop top = (LdsTop)lds_top;
-#else
-    LdsTop top = nullptr;
-#endif
     int x, y;
     bool live = trace_pixel(p, MODE == 1, x, y);
     uint32_t lane = threadIdx.x & 63u;
@@ -940,13 +991,15 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
         const uint32_t nb = (uint32_t)p.bounces;
         uint32_t aux0 = 0xFFFFFFFFu, aux1 = 0u, aux2 = 0u;
         for (uint32_t i = 0; i < nb; i++) {
-            v3 ID = V(1.0f / ps.D.x, 1.0f / ps.D.y, 1.0f / ps.D.z);
+            // fast mode keeps the reciprocal finite, so that no plane distance becomes NaN
+            v3 ID = FAST ? V(fast_rcp(ps.D.x), fast_rcp(ps.D.y), fast_rcp(ps.D.z))
+                         : V(1.0f / ps.D.x, 1.0f / ps.D.y, 1.0f / ps.D.z);
             float best = 1e38f;
             uint32_t code = 0xFFFFFFFFu;
             int sp = 1;
             stack[0] = 0u;
             while (sp > 0)
-                node_step<STATS, RT_TRACE_BLOCK, RT_STACK_LDS, RT_LDS_TOP>(sc, ps.O, ps.D, ID, best, code, sp, stack, spill, st, top);
+                node_step<STATS, RT_TRACE_BLOCK, RT_STACK_LDS, TOP, FAST>(sc, ps.O, ps.D, ID, best, code, sp, stack, spill, st, top);
             nrays++;
             bool exists;
             float thit;
@@ -966,6 +1019,24 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
         }
     }
     flush_counters<STATS>(p.counters, lane, nrays, st);
+}
+
+void launch_trace_fast(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s) {
+    if (p.ntiles == 0) return;
+    const uint32_t mx = (p.tiles_x + RT_MACRO - 1) / RT_MACRO, my = (p.tiles_y + RT_MACRO - 1) / RT_MACRO;
+    const uint32_t groups = ((mx * my + 7u) / 8u) * 8u * (RT_MACRO * RT_MACRO * 4u) / RT_TRACE_WAVES;
+    dim3 grid(groups), block(RT_TRACE_BLOCK);
+#define L(M, A, S) hipLaunchKernelGGL((trace_kernel<M, A, S, true>), grid, block, 0, s, p)
+    if (mode == 0) {
+        if (aux && stats) L(0, true, true);
+        else if (aux) L(0, true, false);
+        else if (stats) L(0, false, true);
+        else L(0, false, false);
+    } else {
+        if (stats) L(1, false, true);
+        else L(1, false, false);
+    }
+#undef L
 }
 
 void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s) {

@@ -9,6 +9,8 @@
 //
 // Pure host code (no GPU): it feeds rt_upload(RT_BINDING_BVH, ...).
 
+#include "rt_fastbvh.h"
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -274,5 +276,26 @@ int rts_build_qbvh(const float *aabb_min, const float *aabb_max, const uint8_t *
 }
 
 void rts_free(void *p) { free(p); }
+
+// The fast-mode tree (rt_fastbvh.cpp) for reference-layout triangle / sphere / box buffers, without
+// a GPU: what rt_set_fast_mode makes the render library build internally.  Output: a malloc'ed
+// array of 16 words per node, *n_nodes_out nodes followed by one sentinel (free with rts_free).
+int rts_build_fast_bvh(const uint32_t *tris, uint32_t n_tris, const uint32_t *spheres, uint32_t n_spheres,
+                       const uint32_t *boxes, uint32_t n_boxes, uint32_t **nodes_out, uint32_t *n_nodes_out) {
+    if (!nodes_out || !n_nodes_out) {
+        g_err = "rts_build_fast_bvh: null output";
+        return 1;
+    }
+    rt::FastBvh b;
+    rt::build_fast_bvh(tris, n_tris, spheres, n_spheres, boxes, n_boxes, b);
+    uint32_t *n = (uint32_t *)malloc(b.nodes.size() * 4);
+    if (!n) {
+        g_err = "rts_build_fast_bvh: out of memory";
+        return 1;
+    }
+    memcpy(n, b.nodes.data(), b.nodes.size() * 4);
+    *nodes_out = n, *n_nodes_out = b.n_nodes;
+    return 0;
+}
 
 }  // extern "C"

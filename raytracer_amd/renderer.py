@@ -145,6 +145,28 @@ class Renderer:
             ex = np.asarray(self.scene_extent, dtype=np.float32).reshape(3).copy()
             _lib.check(self._L.rt_set_scene_bounds(self._ctx, mn.ctypes.data_as(fp), ex.ctypes.data_as(fp)))
 
+    @property
+    def fast_mode(self) -> bool:
+        """Opt-in, default False: traverse the library's own tree (all-axis SAH, conservative 8-bit
+        boxes in 64-byte nodes) instead of the reference's.  Not the reference's data: results
+        differ where the reference's tree decides which hit is found."""
+        return self._fast
+
+    @fast_mode.setter
+    def fast_mode(self, on: bool) -> None:
+        _lib.check(self._L.rt_set_fast_mode(self._ctx, 1 if on else 0))
+        self._fast = bool(on)
+
+    _fast = False
+
+    def fast_bvh(self) -> np.ndarray:
+        """The fast-mode tree as built for the current scene: (n + 1, 16) uint32, the last node a sentinel."""
+        nn = C.c_uint32()
+        _lib.check(self._L.rt_fast_bvh_size(self._ctx, C.byref(nn)))
+        nodes = np.zeros((nn.value + 1, 16), np.uint32)
+        _lib.check(self._L.rt_fast_bvh_export(self._ctx, nodes.ctypes.data_as(C.c_void_p), nodes.nbytes))
+        return nodes
+
     def set_flags(self, aux: bool = False, stats: bool = False) -> None:
         self._flags = (_lib.RT_FLAG_AUX if aux else 0) | (_lib.RT_FLAG_STATS if stats else 0)
 

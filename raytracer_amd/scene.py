@@ -54,6 +54,9 @@ def _scene_lib():
         L.rts_build_qbvh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                      C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32),
                                      C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.rts_build_fast_bvh.restype = C.c_int
+        L.rts_build_fast_bvh.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                         C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32)]
         L.rts_free.restype = None
         L.rts_free.argtypes = [C.c_void_p]
         L.rts_last_error.restype = C.c_char_p
@@ -348,3 +351,22 @@ def load_scene(filepath: str, renderer=None, mesh_override: dict | None = None) 
         renderer = Renderer.get_instance()
     bufs.upload(renderer)
     return bufs
+
+
+def build_fast_bvh(triangles=b"", spheres=b"", boxes=b""):
+    """The fast-mode tree for reference-layout triangle (64 B), sphere (32 B) and box (32 B) buffers,
+    built on the host exactly as the render library builds it when fast mode is switched on: a
+    uint32 array of 16 words per node (layout: csrc/rt_fastbvh.cpp), the last one an all-empty sentinel."""
+    L = _scene_lib()
+    bufs = [np.frombuffer(bytes(np.ascontiguousarray(b).tobytes() if not isinstance(b, (bytes, bytearray)) else b),
+                          dtype=np.uint32).copy() for b in (triangles, spheres, boxes)]
+    nodes = C.POINTER(C.c_uint32)()
+    nn = C.c_uint32()
+    rc = L.rts_build_fast_bvh(bufs[0].ctypes.data, bufs[0].size // 16, bufs[1].ctypes.data, bufs[1].size // 8,
+                              bufs[2].ctypes.data, bufs[2].size // 8, C.byref(nodes), C.byref(nn))
+    if rc != 0:
+        raise RuntimeError(L.rts_last_error().decode())
+    try:
+        return np.ctypeslib.as_array(nodes, shape=((nn.value + 1) * 16,)).copy().reshape(-1, 16)
+    finally:
+        L.rts_free(nodes)
