@@ -135,7 +135,10 @@ def roofline_block(name, args, kernel_ms, rays_per_launch, per_ray):
                 "hbm_counter_frac": traffic / (pmc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "valu_busy": c["SQ_INSTS_VALU"] * issue / (simds * cycles),
                 "valu_lane_util": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]),
+                # the vector-memory path: texture-address and texture-data units, one of each per CU
                 "vmem_issue": c["TA_TA_BUSY_sum"] / (cus * cycles) if "TA_TA_BUSY_sum" in c else None,
+                "vmem_data_return": c["TD_TD_BUSY_sum"] / (cus * cycles) if "TD_TD_BUSY_sum" in c else None,
+                "binds": "vector-memory path (texture-data unit)",
                 "l1_lookups_per_clk_per_cu": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (cus * cycles),
                 "waves_per_simd": c["SQ_WAVE_CYCLES"] * 4.0 / (simds * cycles),
                 "shader_clock_GHz": cycles / (pmc_ms * 1e-3) / 1e9,

@@ -10,7 +10,7 @@ export RT_OVERLAP=0
 run() {
   name=$1; shift
   timeout -s KILL 150 rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/$name" --output-format csv -- python3 "$REPO/bench.py" --no-cpu-baseline --steps 6 --warmup 1 > "$OUT/$name.log" 2>&1
-  for k in "trace_kernel<1" "trace_fast_kernel<1"; do
+  for k in "trace_kernel<1, false, false, false>" "trace_kernel<1, false, false, true>"; do
     echo "== $name $k"; python3 "$REPO/tools/pmc_summary.py" "$OUT/$name" "$k"
   done
 }

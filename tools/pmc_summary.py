@@ -7,7 +7,7 @@ import glob
 import sys
 
 root = sys.argv[1]
-kern = sys.argv[2] if len(sys.argv) > 2 else "trace_kernel<1"
+kern = sys.argv[2] if len(sys.argv) > 2 else "trace_kernel<1, false, false, false>"
 acc = collections.defaultdict(list)
 for fn in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     with open(fn) as f:

@@ -24,7 +24,7 @@ for f in sorted(d.glob("*.txt")):
             counters[name] = val
 g = counters.pop("GRBM_GUI_ACTIVE_per_pass", {})
 counters["GRBM_GUI_ACTIVE"] = sum(g.values()) / max(1, len(g))
-rec = {"kernel": "rt::trace_kernel<1,false,false>", "workload_key": key,
+rec = {"kernel": "rt::trace_kernel<1, false, false, false>", "workload_key": key,
        "kernel_ms_in_pmc_run": sum(durations) / len(durations) / 1e6, "kernel_ms_per_pass": per_pass,
        "valu_issue_cycles": 2.45,
        "valu_issue_cycles_source": "tools/microbench/valu_rate.hip on MI355X: a SIMD issues one independent wave64 "
