@@ -373,6 +373,17 @@ def worker(args):
         if out is not None:
             print(json.dumps(out), flush=True)
         comm.barrier()
+        if rank == 0 and world > 1 and "RT_RDZV_DIR" not in os.environ:
+            # under an external launcher the rendezvous directory is this run's own: leave nothing behind
+            for f in list(comm.rdzv.dir.glob("*")) + list(comm.rdzv.dir.glob(".*")):
+                try:
+                    f.unlink()
+                except OSError:
+                    pass
+            try:
+                comm.rdzv.dir.rmdir()
+            except OSError:
+                pass
     finally:
         r.close()
 

@@ -1,0 +1,82 @@
+"""Ranks + HIP kernels + collectives together on one GPU: two and three rank processes started by
+the library's own launcher render their shards of the same image on GPU 0 and combine them into
+rank 0's sum image.  RCCL refuses several ranks on one device, so the exchange itself goes through
+the host-file stand-in (`Comm(rehearse=True)`); launcher, rendezvous, sharding rules, kernels and
+the finalise step are the real ones.  The RCCL entry points are exercised with a one-rank
+communicator in tests/test_gpu_c5.py."""
+
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from util import GOLDEN, load_golden_scene
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+W, H, BOUNCES, SPP = 320, 180, 4, 12
+
+CHILD = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+    import numpy as np
+    from raytracer_amd import dist as D
+    from raytracer_amd.renderer import Renderer
+    from util import load_golden_scene
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    r = Renderer(device=0, singleton=False)
+    load_golden_scene(r, "gally")
+    r.update_size({w}, {h}); r.bounces = {b}
+    comm = D.Comm(r, rank, world, rehearse=True)
+    r.clear_sum()
+    if {mode!r} == "spp":
+        r.render_sum(0, {spp}, frame_stride=world, frame_phase=rank)
+    else:
+        r.render_sum(0, {spp}, shard=rank, nshards=world)
+    comm.reduce_sum_image(0)
+    total = comm.all_reduce([float(r.stats()["rays"])], "sum")[0]
+    if rank == 0:
+        r.finalize_sum({spp})
+        np.savez({out!r}, sum=r.read_sum(), mean=r.read_accumulation(), rays=total)
+    comm.barrier()
+    r.close()
+""")
+
+
+@pytest.mark.parametrize("world,mode", [(2, "spp"), (3, "tiles")])
+def test_rank_processes_render_shards_on_the_gpu_and_combine(tmp_path, world, mode):
+    from raytracer_amd.renderer import Renderer
+
+    out = str(tmp_path / "combined.npz")
+    code = CHILD.format(root=str(ROOT), w=W, h=H, b=BOUNCES, spp=SPP, mode=mode, out=out)
+    launcher = ("import sys; sys.path.insert(0, %r); from raytracer_amd import dist as D; "
+                "sys.exit(D.spawn_ranks([sys.executable, '-c', %r], %d, timeout=240))" % (str(ROOT), code, world))
+    p = subprocess.run([sys.executable, "-c", launcher], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = np.load(out)
+    # the same image in one process
+    r = Renderer(device=0, singleton=False)
+    try:
+        load_golden_scene(r, "gally")
+        r.update_size(W, H)
+        r.bounces = BOUNCES
+        r.reset_stats()
+        r.clear_sum()
+        r.render_sum(0, SPP)
+        want_sum = r.read_sum()
+        rays = r.stats()["rays"]
+        r.finalize_sum(SPP)
+        want_mean = r.read_accumulation()
+    finally:
+        r.close()
+    assert np.all(got["sum"][..., 3] == SPP)
+    assert float(got["rays"]) == float(rays)
+    if mode == "tiles":   # every pixel is rendered by one rank, all samples in the same order: exact
+        assert np.array_equal(got["sum"].view(np.uint32), want_sum.view(np.uint32))
+        assert np.array_equal(got["mean"].view(np.uint32), want_mean.view(np.uint32))
+    else:                 # samples are added in another order: fp32 reassociation only
+        np.testing.assert_allclose(got["sum"], want_sum, rtol=2e-6, atol=1e-6)
+        assert np.abs(got["mean"] - want_mean).max() <= 1e-5
