@@ -154,6 +154,8 @@ extern "C" int rt_render_noalloc(int device, const rt_scene_view *sv, int width,
     p.scene.n_boxes = sv->n_boxes;
     p.scene.n_planes = sv->n_planes;
     p.scene.n_mats = sv->n_materials;
+    p.scene.fnodes = nullptr;  // fast mode is a context feature; this entry point renders the reference's tree
+    p.scene.n_fnodes = 0;
     for (int i = 0; i < 16; i++) p.scene.inv_vp[i] = sv->inv_view_proj[i];
     for (int i = 0; i < 3; i++) {
         p.scene.eye[i] = sv->eye[i];
