@@ -211,6 +211,8 @@ void trace_frame(rt_ctx *c, const rt::TraceParams &p, int mode, bool aux, bool s
         rt::launch_trace_fast(p, mode, aux, stats, s);
     else if (c->pipeline == 0)
         rt::launch_trace(p, mode, aux, stats, s);
+    else if (c->pipeline == 2)
+        rt::launch_trace_regroup(p, mode, aux, stats, s);
     else
         rt::launch_wavefront_frame(p, c->q, mode, aux, stats, c->extend_waves, c->refill_threshold, c->leaf_threshold, s);
 }
@@ -464,7 +466,7 @@ static int create_impl(rt_ctx *c, int device) {
     // persistent traversal kernel: one 64-lane workgroup per wave slot (32 per CU)
     c->extend_waves = (uint32_t)prop.multiProcessorCount * 32u;
     // experiment knobs (defaults are the tuned values)
-    if (const char *e = getenv("RT_PIPELINE")) c->pipeline = (strcmp(e, "wave") == 0) ? 1 : 0;
+    if (const char *e = getenv("RT_PIPELINE")) c->pipeline = (strcmp(e, "wave") == 0) ? 1 : (strcmp(e, "regroup") == 0) ? 2 : 0;
     if (const char *e = getenv("RT_REFILL")) c->refill_threshold = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_EXTEND_WAVES")) c->extend_waves = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_LEAF")) c->leaf_threshold = (uint32_t)atoi(e);
@@ -588,7 +590,7 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounces, 
     size_t npix = (size_t)c->W * c->H;
     const bool aux = flags & RT_FLAG_AUX, stats = flags & RT_FLAG_STATS;
     // frames that write the per-pixel record, and the wavefront pipeline (one ray queue), run one at a time
-    const bool serial = !c->overlap || aux || c->pipeline != 0;
+    const bool serial = !c->overlap || aux || c->pipeline == 1;
     if (c->tpending[0] || c->tpending[1] || c->sum2_dirty)
         if (int rc = join(c)) return rc;  // sum-mode frames still in flight
     if (aux && !c->aux) {
@@ -736,7 +738,7 @@ int rt_render_sum(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounc
     p.nshards = nshards;
     p.bounces = bounces;
     const uint64_t owned = owned_pixels(p.WW, p.HH, shard, nshards);
-    const bool serial = !c->overlap || c->pipeline != 0;
+    const bool serial = !c->overlap || c->pipeline == 1;
     // odd frames are summed in a second image and folded into the target by the next join; a
     // different target starts a new pair
     if (c->sum2_dirty && c->sum2_target != target)

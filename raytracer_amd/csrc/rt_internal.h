@@ -81,6 +81,8 @@ struct WaveQueues {
 // ---- fast mode: the library's own acceleration structure (rt_fastbvh.h / rt_fastbvh.cpp) -----
 // one frame with the fast-mode traversal (same modes and flags as launch_trace)
 void launch_trace_fast(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s);
+// one frame with the regrouping megakernel (RT_PIPELINE=regroup; same results as launch_trace)
+void launch_trace_regroup(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s);
 
 // repack kernels: reference byte layouts -> device records (n elements + 1 zero-source sentinel)
 void launch_repack_nodes(const uint32_t *src, uint32_t n, const float smin[3], const float sext[3],

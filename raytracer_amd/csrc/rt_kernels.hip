@@ -1021,6 +1021,203 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
     flush_counters<STATS>(p.counters, lane, nrays, st);
 }
 
+// ------------------------------------------------------------------------------------------
+// pipeline A' (RT_PIPELINE=regroup) — the megakernel with the live rays of a workgroup regrouped while
+// they traverse.
+// Rays of one wavefront need very different numbers of node steps, and the wavefront runs until
+// its last ray is done.  Here the four wavefronts of a tile stop every RT_REGROUP_STEPS node steps;
+// if the rays still traversing would fit into fewer wavefronts, those of the emptiest wavefronts
+// ("donors") move into idle lanes of the fullest ones ("keepers") and the donors fall silent for
+// the rest of the bounce.  What moves is origin, direction, best hit and stack height (through a
+// 2 KB LDS buffer); the LDS stack column stays where it is and is addressed by the ray's home
+// thread, the part of a stack that has overflowed into private memory cannot move, so a wavefront
+// holding such a ray is always a keeper.  A ray's own sequence of node visits and intersection
+// tests is untouched: results are those of trace_kernel bit for bit.  Hit distance and primitive
+// return to the home lane through the (then empty) stack column; everything outside traversal
+// runs in the home lane.
+// ------------------------------------------------------------------------------------------
+#ifndef RT_REGROUP_STEPS
+#define RT_REGROUP_STEPS 8
+#endif
+#define RT_RG_TOP 85  // leading nodes in LDS: what is left of 20 KB next to the stack and the transfer buffer
+
+template <int MODE, bool AUX, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_regroup_kernel(TraceParams p) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ float4 lds_top[RT_RG_TOP * RT_TOP_STRIDE];
+    __shared__ float4 xfer[2 * 64];              // a moving ray: O.xyz best | D.xyz primitive
+    __shared__ uint32_t xmeta[64];               //   its stack height | home thread << 8
+    __shared__ uint32_t xvisits[STATS ? 64 : 1];  //   node visits of this ray so far (instrumented builds)
+    __shared__ unsigned long long rg_mask[2][4];  // per round parity and wavefront: lanes with a ray still traversing
+    __shared__ uint32_t rg_pin[2][4];             //   the wavefront holds a ray whose stack reaches into private memory
+    uint32_t spill[RT_STACK_SPILL];
+    const DevScene &sc = p.scene;
+    for (uint32_t k = threadIdx.x; k < RT_RG_TOP * 7u; k += RT_BLOCK) {
+        const uint32_t node = k / 7u, part = k % 7u;
+        lds_top[node * RT_TOP_STRIDE + part] = sc.nodes[(size_t)min(node, sc.n_nodes) * kNodeVec + part];
+    }
+    __syncthreads();
+    LdsTop top = (LdsTop)lds_top;
+    int x, y;
+    const bool live = trace_pixel(p, MODE == 1, x, y);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t nrays = 0, path_visits = 0;
+    Path ps;
+    if (live) primary_ray(sc, p.W, p.H, x, y, p.time, ps);
+    const uint32_t nb = (uint32_t)p.bounces;
+    bool path_alive = live;
+    uint32_t aux0 = 0xFFFFFFFFu, aux1 = 0u, aux2 = 0u;
+    uint32_t round = 0;
+    for (uint32_t i = 0; i < nb; i++) {
+        // the ray this lane traces: first its own
+        v3 O = ps.O, D = ps.D;
+        v3 ID = V(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+        float best = 1e38f;
+        uint32_t code = 0xFFFFFFFFu, slot = threadIdx.x, visits = 0;
+        int sp = path_alive ? 1 : 0;
+        bool has = path_alive;
+        if (has) lds_stack[slot] = 0u;
+        // bit 1 of what a wavefront publishes next to its mask: some path of it was alive at this bounce
+        const uint32_t wave_has_paths = __ballot(path_alive) != 0ull ? 2u : 0u;
+        bool any_path = true;
+        for (;; round++) {
+            for (int k = 0; k < RT_REGROUP_STEPS; k++) {
+                if (__ballot(sp > 0) == 0ull) break;
+                if (sp > 0) {
+                    const uint32_t before = st.nodes;
+                    node_step<STATS, RT_BLOCK, RT_STACK_LDS, RT_RG_TOP>(sc, O, D, ID, best, code, sp, lds_stack + slot, spill, st, top);
+                    if (STATS) visits += st.nodes - before;
+                }
+            }
+            // a finished ray leaves its result in its home column
+            if (has && sp == 0) {
+                lds_stack[slot] = f2u(best);
+                lds_stack[RT_BLOCK + slot] = code;
+                if (STATS) lds_stack[2 * RT_BLOCK + slot] = visits;
+                has = false;
+            }
+            const unsigned long long mine = __ballot(has);
+            const bool pinned = __ballot(has && sp > RT_STACK_LDS) != 0ull;
+            const uint32_t par = round & 1u;
+            if (lane == 0) {
+                rg_mask[par][wave] = mine;
+                rg_pin[par][wave] = (pinned ? 1u : 0u) | wave_has_paths;
+            }
+            __syncthreads();
+            uint32_t cnt[4], key[4], total = 0, npin = 0, paths = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const unsigned long long m = rg_mask[par][w];
+                const uint32_t pn = rg_pin[par][w];
+                cnt[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(m));
+                const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)pn);
+                const uint32_t pin_w = flags & 1u;
+                paths |= flags & 2u;
+                key[w] = cnt[w] + (pin_w << 8);
+                total += cnt[w];
+                npin += pin_w;
+            }
+            if (total == 0u) {
+                any_path = paths != 0u;
+                break;
+            }
+            // keepers: the wavefronts with pinned rays, then the fullest ones, as many as the rays need
+            const uint32_t nkeep = max((total + 63u) / 64u, npin);
+            bool keep[4];
+            uint32_t movers = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                uint32_t rank = 0;
+#pragma unroll
+                for (int v = 0; v < 4; v++) rank += (key[v] > key[w] || (key[v] == key[w] && v < w)) ? 1u : 0u;
+                keep[w] = rank < nkeep;
+                movers += keep[w] ? 0u : cnt[w];
+            }
+            // nothing to move, or (only with pinned wavefronts among the keepers) more than the buffer holds
+            if (movers == 0u || movers > 64u) continue;
+            uint32_t mover_base = 0, hole_base = 0;
+            bool keeper = false;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                if ((uint32_t)w < wave) {
+                    mover_base += keep[w] ? 0u : cnt[w];
+                    hole_base += keep[w] ? 64u - cnt[w] : 0u;
+                }
+                if ((uint32_t)w == wave) keeper = keep[w];
+            }
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+            if (!keeper && has) {
+                const uint32_t m = mover_base + below;
+                xfer[2 * m] = make_float4(O.x, O.y, O.z, best);
+                xfer[2 * m + 1] = make_float4(D.x, D.y, D.z, u2f(code));
+                xmeta[m] = (uint32_t)sp | (slot << 8);
+                if (STATS) xvisits[m] = visits;
+                has = false;
+                sp = 0;
+            }
+            __syncthreads();
+            if (keeper && !has) {
+                const uint32_t h = hole_base + (lane - below);
+                if (h < movers) {
+                    const float4 a = xfer[2 * h], b = xfer[2 * h + 1];
+                    const uint32_t mt = xmeta[h];
+                    O = V(a.x, a.y, a.z), D = V(b.x, b.y, b.z);
+                    ID = V(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+                    best = a.w, code = f2u(b.w);
+                    sp = (int)(mt & 0xFFu), slot = mt >> 8;
+                    if (STATS) visits = xvisits[h];
+                    has = true;
+                }
+            }
+        }
+        round++;
+        if (!any_path) break;  // no path of this tile is alive any more
+        if (path_alive) {
+            best = u2f(lds_stack[threadIdx.x]);
+            code = lds_stack[RT_BLOCK + threadIdx.x];
+            if (STATS) path_visits += lds_stack[2 * RT_BLOCK + threadIdx.x];
+            nrays++;
+            bool exists;
+            float thit;
+            path_alive = bounce<STATS>(sc, ps, best, code, i, exists, thit, st);
+            if (AUX && i == 0) {
+                aux0 = code;
+                aux1 = f2u(thit);
+                aux2 = exists ? 1u : 0u;
+            }
+        }
+    }
+    if (live) {
+        size_t pix = (size_t)y * p.W + x;
+        write_pixel<MODE>(p, pix, ps.light);
+        if (AUX) {
+            reinterpret_cast<uint4 *>(p.aux + pix * 16)[0] = make_uint4(aux0, aux1, aux2, path_visits);
+            write_aux_tail(p.aux, pix, ps, nrays);
+        }
+    }
+    flush_counters<STATS>(p.counters, lane, nrays, st);
+}
+
+void launch_trace_regroup(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s) {
+    if (p.ntiles == 0) return;
+    static_assert(RT_TRACE_WAVES == 4, "trace_pixel must map a workgroup to the four wavefronts of one tile");
+    const uint32_t mx = (p.tiles_x + RT_MACRO - 1) / RT_MACRO, my = (p.tiles_y + RT_MACRO - 1) / RT_MACRO;
+    const uint32_t groups = ((mx * my + 7u) / 8u) * 8u * (RT_MACRO * RT_MACRO);
+    dim3 grid(groups), block(RT_BLOCK);
+#define L(M, A, S) hipLaunchKernelGGL((trace_regroup_kernel<M, A, S>), grid, block, 0, s, p)
+    if (mode == 0) {
+        if (aux && stats) L(0, true, true);
+        else if (aux) L(0, true, false);
+        else if (stats) L(0, false, true);
+        else L(0, false, false);
+    } else {
+        if (stats) L(1, false, true);
+        else L(1, false, false);
+    }
+#undef L
+}
+
 void launch_trace_fast(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s) {
     if (p.ntiles == 0) return;
     const uint32_t mx = (p.tiles_x + RT_MACRO - 1) / RT_MACRO, my = (p.tiles_y + RT_MACRO - 1) / RT_MACRO;

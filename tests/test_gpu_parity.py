@@ -24,9 +24,10 @@ def _cases():
     return out
 
 
-@pytest.fixture(scope="module", params=["wave", "mega"])
+@pytest.fixture(scope="module", params=["wave", "mega", "regroup"])
 def renderer(request):
-    """Both schedulings of the same arithmetic: the wavefront pipeline (default) and the megakernel."""
+    """Every scheduling of the same arithmetic: the wavefront pipeline, the megakernel (default) and
+    the megakernel that regroups a tile's live rays while they traverse."""
     import os
 
     from raytracer_amd.renderer import Renderer
@@ -341,7 +342,7 @@ def test_sum_mode_two_frames_in_flight_is_deterministic(renderer):
         renderer.clear_sum()
         renderer.render_sum(f, 1)
         per_frame.append(read_sum())
-    if renderer.pipeline_name == "mega":
+    if renderer.pipeline_name in ("mega", "regroup"):  # two frames in flight: even and odd frames are summed apart
         even = (per_frame[0] + per_frame[2]) + per_frame[4]
         odd = (per_frame[1] + per_frame[3]) + per_frame[5]
         expect = even + odd
