@@ -107,8 +107,9 @@ struct rt_ctx {
     std::vector<hipEvent_t> ev_trace;  // pairs around trace kernels of the last call
     size_t ev_trace_used = 0;
     bool timed = false;
-    // scheduling of the frame: 0 = megakernel (default: measured faster), 1 = wavefront (ray queue
-    // in HBM, persistent traversal kernel); RT_PIPELINE=wave selects the latter
+    // scheduling of the frame: 0 = megakernel (default: measured fastest), 1 = wavefront (ray queue
+    // in HBM, persistent traversal kernel; RT_PIPELINE=wave), 2 = megakernel that regroups a tile's
+    // live rays while they traverse (RT_PIPELINE=regroup)
     int pipeline = 0;
     rt::WaveQueues q = {{nullptr, nullptr}, nullptr, nullptr};
     uint64_t pixel_samples = 0;  // pixel-samples queued since the last rt_reset_stats
@@ -168,7 +169,7 @@ int alloc_images(rt_ctx *c, int width, int height) {
     const size_t n = (size_t)width * height;
     // ray queue of the wavefront pipeline: one slot per lane of the 16x16 tile grid
     const size_t tiles = (size_t)((width / 8 * 8 + 15) / 16) * (size_t)((height / 4 * 4 + 15) / 16);
-    const size_t slots = ((tiles + 7) / 8) * 8 * 256 + 256;
+    const size_t slots = c->pipeline == 1 ? ((tiles + 7) / 8) * 8 * 256 + 256 : 0;  // only that pipeline has a queue
     void **dst[8] = {(void **)&c->sample, (void **)&c->sample2, (void **)&c->acc,      (void **)&c->sum,
                      (void **)&c->sum2,   (void **)&c->q.rays[0], (void **)&c->q.hits, (void **)&c->q.paths};
     const size_t bytes[8] = {n * sizeof(float4), n * sizeof(float4), n * sizeof(float4), n * sizeof(float4),
@@ -176,6 +177,7 @@ int alloc_images(rt_ctx *c, int width, int height) {
                              slots * 2 * sizeof(float4)};
     void *fresh[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 8; i++) {
+        if (bytes[i] == 0) continue;
         hipError_t e = hipMalloc(&fresh[i], bytes[i]);
         if (e == hipSuccess && i < 5) e = hipMemsetAsync(fresh[i], 0, bytes[i], c->stream);
         if (e != hipSuccess) {
