@@ -35,6 +35,9 @@ namespace rt {
 #ifndef RT_STACK_SPILL
 #define RT_STACK_SPILL 56
 #endif
+#ifndef RT_ASM_LOADS
+#define RT_ASM_LOADS 1  // node loads written in assembly (node_load); 0 = left to the compiler, 0.7 % slower
+#endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 8  // megakernel: waves per SIMD the register allocator must leave room for
 #endif
@@ -436,6 +439,47 @@ __device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeR
         return;
     }
     ni = min(ni, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
+#if RT_ASM_LOADS
+    if (TOP > 0) {
+        // Written in assembly so that the two cases may be in flight together: in a wavefront whose
+        // lanes split between them the compiler would wait for all global loads before it issues the
+        // LDS reads, because both write the same registers (in different lanes, which it cannot know).
+        vec4f a0, a1, a2, a3, a4, a5, a6;
+        if (ni < (uint32_t)TOP) {
+            const uint32_t addr = (uint32_t)(uintptr_t)top + ni * (RT_TOP_STRIDE * 16u);
+            asm volatile(
+                "ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:32\n\t"
+                "ds_read_b128 %3, %7 offset:48\n\tds_read_b128 %4, %7 offset:64\n\tds_read_b128 %5, %7 offset:80\n\t"
+                "ds_read_b128 %6, %7 offset:96"
+                : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6)
+                : "v"(addr)
+                : "memory");
+        } else {
+            const float4 *np = sc.nodes + (size_t)ni * kNodeVec;
+            asm volatile(
+                "global_load_dwordx4 %0, %7, off\n\tglobal_load_dwordx4 %1, %7, off offset:16\n\t"
+                "global_load_dwordx4 %2, %7, off offset:32\n\tglobal_load_dwordx4 %3, %7, off offset:48\n\t"
+                "global_load_dwordx4 %4, %7, off offset:64\n\tglobal_load_dwordx4 %5, %7, off offset:80\n\t"
+                "global_load_dwordx4 %6, %7, off offset:96"
+                : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6)
+                : "v"(np)
+                : "memory");
+        }
+        // either kind returns in order: vector k has arrived when at most 6 - k of its kind are outstanding
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(6)" : "+v"(a0));
+        asm volatile("s_waitcnt vmcnt(5) lgkmcnt(5)" : "+v"(a1));
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(4)" : "+v"(a2));
+        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(3)" : "+v"(a3));
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(2)" : "+v"(a4));
+        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(1)" : "+v"(a5));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a6));
+        nd.lox = make_float4(a0.x, a0.y, a0.z, a0.w), nd.hix = make_float4(a1.x, a1.y, a1.z, a1.w);
+        nd.loy = make_float4(a2.x, a2.y, a2.z, a2.w), nd.hiy = make_float4(a3.x, a3.y, a3.z, a3.w);
+        nd.loz = make_float4(a4.x, a4.y, a4.z, a4.w), nd.hiz = make_float4(a5.x, a5.y, a5.z, a5.w);
+        nd.mt = make_float4(a6.x, a6.y, a6.z, a6.w);
+        return;
+    }
+#endif
     if (TOP > 0 && ni < (uint32_t)TOP) {
         LdsTop tp = top + ni * RT_TOP_STRIDE;
         nd.lox = ld4(tp), nd.hix = ld4(tp + 1), nd.loy = ld4(tp + 2), nd.hiy = ld4(tp + 3), nd.loz = ld4(tp + 4),
