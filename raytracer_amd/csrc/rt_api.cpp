@@ -271,7 +271,8 @@ int repack(rt_ctx *c, int binding) {
     if (!b->dirty) return 0;
     if (int rc = sync_all(c)) return rc;  // frames in flight still read the old records
     c->main_dirty = true;
-    size_t need = ((size_t)b->count + 1) * vecs_per_elem(binding);
+    // + 8: the traversal fetches records by the 128-byte line, so the line of the last record must be readable
+    size_t need = ((size_t)b->count + 1) * vecs_per_elem(binding) + 8;
     if (need > b->packed_cap) {
         if (b->packed) HIP_TRY(hipFree(b->packed));
         b->packed = nullptr;

@@ -38,6 +38,9 @@ namespace rt {
 #ifndef RT_ASM_LOADS
 #define RT_ASM_LOADS 1  // node loads written in assembly (node_load); 0 = left to the compiler, 0.7 % slower
 #endif
+#ifndef RT_UNIFIED
+#define RT_UNIFIED 1  // megakernel: one kind of step for nodes and leaves (traverse_unified)
+#endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 8  // megakernel: waves per SIMD the register allocator must leave room for
 #endif
@@ -671,6 +674,114 @@ __device__ __forceinline__ void node_step(const DevScene &sc, v3 O, v3 D, v3 ID,
     while (ll.n > 0) leaf_one<STATS>(sc, O, D, best, best_code, ll, st);
 }
 
+// The whole traversal of one ray (compute.glsl:225-330) with ONE kind of step for nodes and
+// leaves: every lane holds the item it works on next -- a node to visit or a leaf primitive to
+// intersect -- and a step fetches the item's record and processes it.  A lane's own sequence (node,
+// its leaves far to near, next node, ...) is exactly that of node_step, so the results are the
+// same; what changes is what the wavefront pays.  The CU's vector-memory return path charges 16
+// cycles per load instruction however few lanes are active and waits for the cache once per batch
+// of loads that miss; with leaves intersected in steps of their own, a wavefront issued 7 loads per
+// node step plus 3 per leaf step, the latter for 6 active lanes on average.  Here the lanes that
+// are at a leaf ride along in the 7 loads of the lanes that are at a node: the loads fetch the
+// first 112 bytes of the 128-byte line the item's record lies in (records never straddle lines:
+// nodes take a line, two triangles or four spheres share one), and a leaf lane picks its record
+// out of them.  Boxes (two records of four would not fit) keep loads of their own.
+template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP>
+__device__ __forceinline__ void traverse_unified(const DevScene &sc, v3 O, v3 D, v3 ID, float &best,
+                                                 uint32_t &best_code, uint32_t *stack, uint32_t *spill, LaneStats &st,
+                                                 LdsTop top) {
+    int sp = 0;
+    uint32_t cur = 0xC0000000u;  // the root node
+    bool have = true;
+    LeafList ll = {0u, 0u, 0u, 0u, 0};
+    if (STATS) st.max_sp = max(st.max_sp, 1u);  // the reference pushes the root before its loop
+    while (have) {
+        const uint32_t type = cur >> 30, idx = cur & 0x3FFFFFFFu;
+        const uint32_t ni = min(idx, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
+        const bool in_lds = type == 3u && ni < (uint32_t)TOP;
+        vec4f a0, a1, a2, a3, a4, a5, a6;
+        uintptr_t rec = 0;  // address of the item's record
+        if (in_lds) {
+            const uint32_t addr = (uint32_t)(uintptr_t)top + ni * (RT_TOP_STRIDE * 16u);
+            asm volatile(
+                "ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:32\n\t"
+                "ds_read_b128 %3, %7 offset:48\n\tds_read_b128 %4, %7 offset:64\n\tds_read_b128 %5, %7 offset:80\n\t"
+                "ds_read_b128 %6, %7 offset:96"
+                : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6)
+                : "v"(addr)
+                : "memory");
+        } else {
+            if (type == 3u) rec = (uintptr_t)(sc.nodes + (size_t)ni * kNodeVec);
+            else if (type == 0u) rec = (uintptr_t)(sc.tris + (size_t)min(idx, sc.n_tris) * kTriVec);
+            else if (type == 1u) rec = (uintptr_t)(sc.spheres + (size_t)min(idx, sc.n_spheres) * kSphereVec);
+            else rec = (uintptr_t)(sc.boxes + (size_t)min(idx, sc.n_boxes) * 2);
+            const float4 *line = reinterpret_cast<const float4 *>(rec & ~(uintptr_t)127);
+            asm volatile(
+                "global_load_dwordx4 %0, %7, off\n\tglobal_load_dwordx4 %1, %7, off offset:16\n\t"
+                "global_load_dwordx4 %2, %7, off offset:32\n\tglobal_load_dwordx4 %3, %7, off offset:48\n\t"
+                "global_load_dwordx4 %4, %7, off offset:64\n\tglobal_load_dwordx4 %5, %7, off offset:80\n\t"
+                "global_load_dwordx4 %6, %7, off offset:96"
+                : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6)
+                : "v"(line)
+                : "memory");
+        }
+        // either kind returns in order: vector k has arrived when at most 6 - k of its kind are outstanding
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(6)" : "+v"(a0));
+        asm volatile("s_waitcnt vmcnt(5) lgkmcnt(5)" : "+v"(a1));
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(4)" : "+v"(a2));
+        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(3)" : "+v"(a3));
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(2)" : "+v"(a4));
+        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(1)" : "+v"(a5));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a6));
+#define F4(a) make_float4(a.x, a.y, a.z, a.w)
+        if (type == 3u) {
+            if (STATS) st.nodes++;
+            NodeRegs nd;
+            nd.lox = F4(a0), nd.hix = F4(a1), nd.loy = F4(a2), nd.hiy = F4(a3), nd.loz = F4(a4), nd.hiz = F4(a5), nd.mt = F4(a6);
+            node_test<STATS, STRIDE, LDS_DEPTH, false>(sc, nd, O, ID, best, sp, stack, spill, ll, st);
+        } else {
+            float t;
+            bool hit;
+            if (type == 0u) {
+                const bool upper = (rec & 64u) != 0u;  // second record of its line
+                if (STATS) st.tri++;
+                hit = tri_distance(O, D, upper ? F4(a4) : F4(a0), upper ? F4(a5) : F4(a1), upper ? F4(a6) : F4(a2), t);
+            } else if (type == 1u) {
+                const uint32_t q = (uint32_t)(rec >> 5) & 3u;  // which of the four records of its line
+                const vec4f s0 = q == 0u ? a0 : q == 1u ? a2 : q == 2u ? a4 : a6;
+                if (STATS) st.sph++;
+                hit = sphere_distance(O, D, F4(s0), t);
+            } else {
+                const float4 *bp = reinterpret_cast<const float4 *>(rec);
+                float4 b0 = bp[0], b1 = bp[1];
+                if (STATS) st.box++;
+                hit = box_distance(O, D, V(b0.x, b0.y, b0.z), V(b1.x, b1.y, b1.z), t);
+            }
+            if (hit && t > 0.0f && t < best - 1e-6f) {
+                best = t;
+                best_code = cur;
+            }
+        }
+#undef F4
+        // the next item: the nearest pending leaf of the node just visited, else the next node
+        // (written with selects and one converging branch: the loop must keep a single back edge, or
+        // the compiler nests it and the lanes at a leaf hold up the lanes at a node again)
+        const bool from_list = ll.n > 0;
+        const bool from_stack = !from_list && sp > 0;
+        uint32_t popped = 0u;
+        if (from_stack) {
+            if (STATS) st.max_sp = max(st.max_sp, (uint32_t)sp);
+            popped = 0xC0000000u | stack_pop<STRIDE, LDS_DEPTH>(sp, stack, spill);
+        }
+        cur = from_list ? ll.l0 : popped;
+        ll.l0 = from_list ? ll.l1 : ll.l0;
+        ll.l1 = from_list ? ll.l2 : ll.l1;
+        ll.l2 = from_list ? ll.l3 : ll.l2;
+        ll.n -= from_list ? 1 : 0;
+        have = from_list || from_stack;
+    }
+}
+
 // Surface attributes of the accepted primitive, derived from (O, D, t, code) exactly as the
 // intersection routines derive them (compute.glsl:838-843, :909-916, :944-961).
 __device__ __forceinline__ void hit_attributes(const DevScene &sc, v3 O, v3 D, float t, uint32_t code, v3 &pos,
@@ -1040,10 +1151,17 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
                          : V(1.0f / ps.D.x, 1.0f / ps.D.y, 1.0f / ps.D.z);
             float best = 1e38f;
             uint32_t code = 0xFFFFFFFFu;
-            int sp = 1;
-            stack[0] = 0u;
-            while (sp > 0)
-                node_step<STATS, RT_TRACE_BLOCK, RT_STACK_LDS, TOP, FAST>(sc, ps.O, ps.D, ID, best, code, sp, stack, spill, st, top);
+#if RT_UNIFIED
+            if (!FAST) {
+                traverse_unified<STATS, RT_TRACE_BLOCK, RT_STACK_LDS, TOP>(sc, ps.O, ps.D, ID, best, code, stack, spill, st, top);
+            } else
+#endif
+            {
+                int sp = 1;
+                stack[0] = 0u;
+                while (sp > 0)
+                    node_step<STATS, RT_TRACE_BLOCK, RT_STACK_LDS, TOP, FAST>(sc, ps.O, ps.D, ID, best, code, sp, stack, spill, st, top);
+            }
             nrays++;
             bool exists;
             float thit;
