@@ -686,16 +686,33 @@ __device__ __forceinline__ void node_step(const DevScene &sc, v3 O, v3 D, v3 ID,
 // first 112 bytes of the 128-byte line the item's record lies in (records never straddle lines:
 // nodes take a line, two triangles or four spheres share one), and a leaf lane picks its record
 // out of them.  Boxes (two records of four would not fit) keep loads of their own.
-template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP>
-__device__ __forceinline__ void traverse_unified(const DevScene &sc, v3 O, v3 D, v3 ID, float &best,
-                                                 uint32_t &best_code, uint32_t *stack, uint32_t *spill, LaneStats &st,
-                                                 LdsTop top) {
-    int sp = 0;
-    uint32_t cur = 0xC0000000u;  // the root node
-    bool have = true;
-    LeafList ll = {0u, 0u, 0u, 0u, 0};
+// Where a lane stands in the traversal of its ray: the item it works on next (a child word: a node
+// to visit or a leaf primitive to intersect), the pending leaves of the node visited last, the stack
+// height.  `have` is false once the ray is done.
+struct Walk {
+    uint32_t cur;
+    LeafList ll;
+    int sp;
+    bool have;
+};
+template <bool STATS>
+__device__ __forceinline__ void walk_begin(Walk &w, LaneStats &st) {
+    w.cur = 0xC0000000u;  // the root node
+    w.ll = {0u, 0u, 0u, 0u, 0};
+    w.sp = 0;
+    w.have = true;
     if (STATS) st.max_sp = max(st.max_sp, 1u);  // the reference pushes the root before its loop
-    while (have) {
+}
+
+// One step of traverse_unified (below) for the lanes that call it.
+template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP>
+__device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID, float &best, uint32_t &best_code,
+                                          Walk &w, uint32_t *stack, uint32_t *spill, LaneStats &st, LdsTop top) {
+    uint32_t &cur = w.cur;
+    LeafList &ll = w.ll;
+    int &sp = w.sp;
+    bool &have = w.have;
+    {
         const uint32_t type = cur >> 30, idx = cur & 0x3FFFFFFFu;
         const uint32_t ni = min(idx, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
         const bool in_lds = type == 3u && ni < (uint32_t)TOP;
@@ -780,6 +797,15 @@ __device__ __forceinline__ void traverse_unified(const DevScene &sc, v3 O, v3 D,
         ll.n -= from_list ? 1 : 0;
         have = from_list || from_stack;
     }
+}
+
+template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP>
+__device__ __forceinline__ void traverse_unified(const DevScene &sc, v3 O, v3 D, v3 ID, float &best,
+                                                 uint32_t &best_code, uint32_t *stack, uint32_t *spill, LaneStats &st,
+                                                 LdsTop top) {
+    Walk w;
+    walk_begin<STATS>(w, st);
+    while (w.have) walk_step<STATS, STRIDE, LDS_DEPTH, TOP>(sc, O, D, ID, best, best_code, w, stack, spill, st, top);
 }
 
 // Surface attributes of the accepted primitive, derived from (O, D, t, code) exactly as the
