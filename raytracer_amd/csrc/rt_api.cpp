@@ -125,7 +125,6 @@ struct rt_ctx {
     double *comm_scratch = nullptr;
     uint32_t extend_waves = 8192;
     uint32_t refill_threshold = 16;
-    uint32_t leaf_threshold = 8;
 };
 
 namespace {
@@ -216,7 +215,7 @@ void trace_frame(rt_ctx *c, const rt::TraceParams &p, int mode, bool aux, bool s
     else if (c->pipeline == 2)
         rt::launch_trace_regroup(p, mode, aux, stats, s);
     else
-        rt::launch_wavefront_frame(p, c->q, mode, aux, stats, c->extend_waves, c->refill_threshold, c->leaf_threshold, s);
+        rt::launch_wavefront_frame(p, c->q, mode, aux, stats, c->extend_waves, c->refill_threshold, s);
 }
 
 // Makes `stream` depend on everything queued on the trace streams and folds the odd frames' sum
@@ -472,9 +471,6 @@ static int create_impl(rt_ctx *c, int device) {
     if (const char *e = getenv("RT_PIPELINE")) c->pipeline = (strcmp(e, "wave") == 0) ? 1 : (strcmp(e, "regroup") == 0) ? 2 : 0;
     if (const char *e = getenv("RT_REFILL")) c->refill_threshold = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_EXTEND_WAVES")) c->extend_waves = (uint32_t)atoi(e);
-    if (const char *e = getenv("RT_LEAF")) c->leaf_threshold = (uint32_t)atoi(e);
-    if (c->leaf_threshold < 1u) c->leaf_threshold = 1u;
-    if (c->leaf_threshold > 64u) c->leaf_threshold = 64u;
     if (c->refill_threshold < 1u) c->refill_threshold = 1u;
     if (c->refill_threshold > 64u) c->refill_threshold = 64u;
     if (c->extend_waves < 1u) c->extend_waves = 1u;

@@ -1496,13 +1496,13 @@ __global__ __launch_bounds__(RT_BLOCK) void generate_kernel(TraceParams p, WaveQ
 // generated by workgroups of the same XCD under round-robin placement, so their nodes are in that
 // XCD's L2); within its XCD's region wavefront w of the Wx resident there owns the 64-slot chunks
 // w, w + Wx, w + 2 Wx, ...: a static interleaved partition, so nothing is claimed through memory.
-// Lanes whose stack is empty retire their result and are refilled in batches; every lane with
-// work performs one node step per iteration.  A wavefront ends when its chunks are used up and
-// every lane is idle.  The workgroup shares one LDS copy of the top of the tree.
+// Lanes whose ray is done retire their result and are refilled in batches; every lane with work
+// performs one step (a node visit or a leaf intersection: walk_step) per iteration.  A wavefront
+// ends when its chunks are used up and every lane is idle.  The workgroup shares one LDS copy of
+// the top of the tree.
 template <bool STATS>
 __global__ __launch_bounds__(RT_BLOCK, RT_EXTEND_MIN_WAVES) void extend_kernel(DevScene sc, WaveQueues q, uint32_t n_slots,
-                                                                              uint32_t refill_threshold,
-                                                                              uint32_t leaf_threshold, Counters *counters,
+                                                                              uint32_t refill_threshold, Counters *counters,
                                                                               uint32_t *aux) {
     __shared__ uint32_t lds_stack[RT_EXT_STACK_LDS * RT_BLOCK];
     uint32_t spill[RT_STACK_SPILL];
@@ -1531,14 +1531,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_EXTEND_MIN_WAVES) void extend_kernel(D
     uint32_t cur = chunk * 64u, end = min(cur + 64u, n_slots);
     bool exhausted = chunk >= region_end;
     int ray = -1;
-    int sp = 0;
     v3 O = V(0, 0, 0), D = V(0, 0, 0), ID = V(0, 0, 0);
     float best = 1e38f;
     uint32_t code = 0xFFFFFFFFu;
     uint32_t nodes_this_ray = 0, pix_this_ray = 0;
-    LeafList ll = {0, 0, 0, 0, 0};
+    Walk w;
+    w.cur = 0u, w.ll = {0u, 0u, 0u, 0u, 0}, w.sp = 0, w.have = false;
     for (;;) {
-        bool idle = (sp == 0) && (ll.n == 0);
+        bool idle = !w.have;
         unsigned long long idle_mask = __ballot(idle);
         uint32_t n_idle = (uint32_t)__popcll(idle_mask);
         if (n_idle >= refill_threshold || n_idle == 64u) {
@@ -1567,8 +1567,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_EXTEND_MIN_WAVES) void extend_kernel(D
                             ID = V(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
                             best = 1e38f;
                             code = 0xFFFFFFFFu;
-                            stack[0] = 0u;
-                            sp = 1;
+                            walk_begin<STATS>(w, st);
                             nodes_this_ray = 0;
                         }
                     }
@@ -1582,20 +1581,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_EXTEND_MIN_WAVES) void extend_kernel(D
                     }
                 }
             }
-            if (exhausted && __ballot(sp > 0 || ll.n > 0) == 0ull) break;
+            if (exhausted && __ballot(w.have) == 0ull) break;
         }
-        // A lane with pending leaves waits (it must intersect them before its next pop, to keep
-        // the reference's order) while the others go on with node steps; the wavefront switches
-        // to a leaf iteration once enough lanes are waiting, or nobody can do a node step.
-        bool pending = ll.n > 0;
-        bool node_ready = (sp > 0) && !pending;
-        uint32_t n_pending = (uint32_t)__popcll(__ballot(pending));
-        bool any_node = __ballot(node_ready) != 0ull;
-        if (n_pending >= leaf_threshold || (n_pending > 0u && !any_node)) {
-            if (pending) leaf_one<STATS>(sc, O, D, best, code, ll, st);
-        } else if (node_ready) {
-            if (STATS) nodes_this_ray++;
-            node_part<STATS, 64, RT_EXT_STACK_LDS, RT_LDS_TOP>(sc, O, ID, best, sp, stack, spill, ll, st, top);
+        if (w.have) {
+            const uint32_t visits_before = st.nodes;
+            walk_step<STATS, 64, RT_EXT_STACK_LDS, RT_LDS_TOP>(sc, O, D, ID, best, code, w, stack, spill, st, top);
+            if (STATS) nodes_this_ray += st.nodes - visits_before;
         }
     }
     flush_counters<STATS>(counters, lane, nrays_done, st);
@@ -1651,7 +1642,7 @@ __global__ __launch_bounds__(RT_BLOCK) void shade_kernel(TraceParams p, WaveQueu
 }
 
 void launch_wavefront_frame(const TraceParams &p, const WaveQueues &q, int mode, bool aux, bool stats,
-                            uint32_t extend_waves, uint32_t refill_threshold, uint32_t leaf_threshold, hipStream_t s) {
+                            uint32_t extend_waves, uint32_t refill_threshold, hipStream_t s) {
     uint32_t per = (p.ntiles + 7u) / 8u;
     if (per == 0) return;
     const uint32_t nb_raw = (uint32_t)p.bounces;
@@ -1673,10 +1664,10 @@ void launch_wavefront_frame(const TraceParams &p, const WaveQueues &q, int mode,
     for (uint32_t b = 0; b < nb; b++) {
         if (stats)
             hipLaunchKernelGGL((extend_kernel<true>), dim3(egroups), dim3(RT_BLOCK), 0, s, p.scene, q, n_slots,
-                               refill_threshold, leaf_threshold, p.counters, aux ? p.aux : nullptr);
+                               refill_threshold, p.counters, aux ? p.aux : nullptr);
         else
             hipLaunchKernelGGL((extend_kernel<false>), dim3(egroups), dim3(RT_BLOCK), 0, s, p.scene, q, n_slots,
-                               refill_threshold, leaf_threshold, p.counters, (uint32_t *)nullptr);
+                               refill_threshold, p.counters, (uint32_t *)nullptr);
 #define S(M, A, T) hipLaunchKernelGGL((shade_kernel<M, A, T>), tgrid, block, 0, s, p, q, n_slots, b)
         if (mode == 0) {
             if (aux && stats) S(0, true, true);
