@@ -150,6 +150,7 @@ def run_c4(args, r, comm, rank, world, name, bufs, build_s, rehearse):
     """1080p frames: `rt_render` at one GPU, spp-sharded `rt_render_sum` + one reduce at N GPUs."""
     from raytracer_amd.camera import Camera
 
+    variant, _ = r.traversal_variant()   # chosen by the library on the first frames of this scene
     npix = args.width * args.height
     # per-ray work of this workload, from one untimed instrumented frame (counter kernel variant)
     r.set_flags(stats=True)
@@ -263,7 +264,9 @@ def run_c4(args, r, comm, rank, world, name, bufs, build_s, rehearse):
         "sum_mode": {"value": tsum[1] / tmax[1] / 1e6, "unit": "Mrays/s", "ms_per_step": tmax[1] / args.steps * 1e3,
                      "what": "the same loop through rt_render_sum (linear radiance sum, no sRGB encode, no accumulate "
                              "pass): the per-GPU step of the multi-GPU runs, comparable across n_gpus"},
-        "roofline": roofline_block(name, args, kernel_ms, rays_per_launch, per_ray),
+        "roofline": dict(roofline_block(name, args, kernel_ms, rays_per_launch, per_ray),
+                         kernel="trace_leafstep_kernel" if variant == "leaf steps" else "trace_kernel",
+                         traversal_variant=variant),
     }
     if world == 1:
         out["fast_mode"] = fast
@@ -364,6 +367,11 @@ def worker(args):
         r.update_size(args.width, args.height)
         bufs.upload(r)
         r.bounces = args.bounces
+        # The library times its two traversal variants before the first plain frame of a scene
+        # (rt_traversal_variant in the header) and keeps the faster: let that happen before any timing.
+        r.render_sum(first_frame=0, nframes=1)
+        r.sync()
+        r.clear_sum()
         comm = D.Comm(r, rank, world, rehearse=rehearse)
         joined = comm.all_reduce([1.0], "sum")[0]
         if int(round(joined)) != args.gpus:

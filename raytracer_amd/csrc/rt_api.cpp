@@ -123,6 +123,16 @@ struct rt_ctx {
     void *comm = nullptr;  // RCCL communicator (rt_comm_init)
     int comm_rank = 0, comm_world = 1;
     double *comm_scratch = nullptr;
+    // Traversal variant of the megakernel (rt_kernels.hip, trace_body): the unified node / leaf step
+    // or leaf steps of their own.  Neither wins everywhere, so before the first plain frame of a
+    // scene four extra launches that write nothing are timed -- leaf steps, unified (both to get the
+    // kernels loaded and the caches warm), then leaf steps and unified again -- and the faster of
+    // the last two is kept until the scene or the image size changes.  RT_LEAF_STEPS=0 / 1 fixes it.
+    int leaf_steps = 0;
+    bool tuned = false, tune_fixed = false;
+    float tune_ms[4] = {0.f, 0.f, 0.f, 0.f};
+    hipEvent_t ev_tune[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    rt::Counters *tune_counters = nullptr;  // where those launches count their rays
     uint32_t extend_waves = 8192;
     uint32_t refill_threshold = 16;
 };
@@ -211,7 +221,7 @@ void trace_frame(rt_ctx *c, const rt::TraceParams &p, int mode, bool aux, bool s
     if (c->fast)
         rt::launch_trace_fast(p, mode, aux, stats, s);
     else if (c->pipeline == 0)
-        rt::launch_trace(p, mode, aux, stats, s);
+        rt::launch_trace(p, mode, aux, stats, c->leaf_steps != 0, s);
     else if (c->pipeline == 2)
         rt::launch_trace_regroup(p, mode, aux, stats, s);
     else
@@ -400,6 +410,31 @@ uint64_t owned_pixels(int WW, int HH, uint32_t shard, uint32_t nshards) {
     return n;
 }
 
+// Times the two traversal variants on this scene, image size and shard (see rt_ctx::leaf_steps) with
+// launches that write no image and count their rays apart.  Runs once, before the first plain frame.
+int choose_traversal_variant(rt_ctx *c, const rt::TraceParams &frame) {
+    if (c->tuned || c->tune_fixed || c->pipeline != 0 || c->fast) return 0;
+    if (int rc = join(c)) return rc;
+    c->main_dirty = true;
+    rt::TraceParams q = frame;
+    q.sample = nullptr;
+    q.sum = nullptr;
+    q.aux = nullptr;
+    q.counters = c->tune_counters;
+    q.time = 0.0f;
+    for (int k = 0; k < 4; k++) {
+        HIP_TRY(hipEventRecord(c->ev_tune[k], c->stream));
+        rt::launch_trace(q, 0, false, false, (k & 1) == 0, c->stream);
+    }
+    HIP_TRY(hipEventRecord(c->ev_tune[4], c->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventSynchronize(c->ev_tune[4]));
+    for (int k = 0; k < 4; k++) HIP_TRY(hipEventElapsedTime(&c->tune_ms[k], c->ev_tune[k], c->ev_tune[k + 1]));
+    c->leaf_steps = c->tune_ms[2] < c->tune_ms[3] ? 1 : 0;
+    c->tuned = true;
+    return 0;
+}
+
 int begin_timed(rt_ctx *c) {
     HIP_TRY(hipEventRecord(c->ev_begin, c->stream));
     c->ev_trace_used = 0;
@@ -459,7 +494,14 @@ static int create_impl(rt_ctx *c, int device) {
         HIP_TRY(hipEventCreateWithFlags(&c->ev_acc[b], hipEventDisableTiming));
         HIP_TRY(hipEventCreate(&c->ev_tlast[b]));
     }
+    for (hipEvent_t &e : c->ev_tune) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipMalloc((void **)&c->tune_counters, sizeof(rt::Counters) * rt::kCounterStripes));
+    HIP_TRY(hipMemsetAsync(c->tune_counters, 0, sizeof(rt::Counters) * rt::kCounterStripes, c->stream));
     if (const char *e = getenv("RT_OVERLAP")) c->overlap = atoi(e) != 0;
+    if (const char *e = getenv("RT_LEAF_STEPS")) {
+        c->leaf_steps = atoi(e) != 0;
+        c->tune_fixed = true;
+    }
     HIP_TRY(hipMalloc((void **)&c->counters, sizeof(rt::Counters) * rt::kCounterStripes));
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(rt::Counters) * rt::kCounterStripes, c->stream));
     HIP_TRY(hipMalloc((void **)&c->comm_scratch, sizeof(double) * RT_COMM_MAX_SCALARS));
@@ -517,6 +559,9 @@ int rt_destroy(rt_ctx *c) {
                     (void *)c->q.hits, (void *)c->q.paths})
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_trace) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_tune)
+        if (e) (void)hipEventDestroy(e);
+    if (c->tune_counters) (void)hipFree(c->tune_counters);
     for (hipEvent_t e : {c->ev_begin, c->ev_end, c->ev_ready, c->ev_tdone[0], c->ev_tdone[1], c->ev_acc[0], c->ev_acc[1],
                          c->ev_tlast[0], c->ev_tlast[1]})
         if (e) (void)hipEventDestroy(e);
@@ -532,6 +577,7 @@ int rt_resize(rt_ctx *c, int width, int height) {
     if ((size_t)width * (size_t)height > ((size_t)1 << 28)) return fail("rt_resize: image too large");
     HIP_TRY(hipSetDevice(c->device));
     if (int rc = sync_all(c)) return rc;
+    c->tuned = false;
     return alloc_images(c, width, height);
 }
 
@@ -554,6 +600,7 @@ int rt_upload(rt_ctx *c, int binding, const void *data, size_t nbytes) {
         // the caller's array may be reused as soon as this returns, as with glBufferData
         HIP_TRY(hipMemcpy(b->raw, data, nbytes, hipMemcpyHostToDevice));
     }
+    if (binding != RT_BINDING_MATERIALS) c->tuned = false;  // a new scene: time the variants again
     if (binding == RT_BINDING_BVH) c->host_nodes.assign((const uint32_t *)data, (const uint32_t *)data + nbytes / 4);
     if (binding == RT_BINDING_TRIANGLES || binding == RT_BINDING_SPHERES || binding == RT_BINDING_BOXES) {
         std::vector<uint32_t> &h = binding == RT_BINDING_TRIANGLES ? c->host_tris
@@ -598,6 +645,8 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounces, 
     if (aux) HIP_TRY(hipMemsetAsync(c->aux, 0, npix * 16 * sizeof(uint32_t), c->stream));
     p.aux = aux ? c->aux : nullptr;
     p.bounces = bounces;
+    if (!aux && !stats && nframes)
+        if (int rc = choose_traversal_variant(c, p)) return rc;
     if (int rc = begin_timed(c)) return rc;
     for (uint32_t i = 0; i < nframes; i++) {
         p.time = (float)(first_frame + i);  // renderer.py:211 float(self._frames)
@@ -742,6 +791,8 @@ int rt_render_sum(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounc
     // different target starts a new pair
     if (c->sum2_dirty && c->sum2_target != target)
         if (int rc = join(c)) return rc;
+    if (frame_phase < nframes)
+        if (int rc = choose_traversal_variant(c, p)) return rc;
     if (int rc = begin_timed(c)) return rc;
     for (uint32_t i = frame_phase; i < nframes; i += frame_stride) {
         p.time = (float)(first_frame + i);
@@ -792,6 +843,13 @@ int rt_fast_bvh_export(rt_ctx *c, void *nodes, size_t nodes_bytes) {
     if (nodes_bytes != c->fbvh.nodes.size() * 4)
         return fail("rt_fast_bvh_export: the buffer must hold 64 bytes times (the count rt_fast_bvh_size reports + 1)");
     memcpy(nodes, c->fbvh.nodes.data(), nodes_bytes);
+    return 0;
+}
+
+int rt_traversal_variant(rt_ctx *c, int *leaf_steps, int *decided) {
+    if (!c || !leaf_steps || !decided) return fail("rt_traversal_variant: null argument");
+    *leaf_steps = c->leaf_steps;
+    *decided = (c->tune_fixed || c->tuned) ? 1 : 0;
     return 0;
 }
 

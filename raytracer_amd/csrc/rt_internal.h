@@ -93,7 +93,8 @@ void launch_repack_mats(const uint32_t *src, uint32_t n, float4 *dst, hipStream_
 void launch_copy_raw32(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s);  // boxes/planes + sentinel
 
 // mode 0 = reference frame (writes sample), mode 1 = add linear radiance into sum
-void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s);
+// leaf_steps: the variant with leaf steps of their own instead of the unified node / leaf step
+void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, bool leaf_steps, hipStream_t s);
 // one frame through the wavefront pipeline: generate, then per bounce extend + shade
 void launch_wavefront_frame(const TraceParams &p, const WaveQueues &q, int mode, bool aux, bool stats,
                             uint32_t extend_waves, uint32_t refill_threshold, hipStream_t s);

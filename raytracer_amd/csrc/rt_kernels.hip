@@ -38,9 +38,6 @@ namespace rt {
 #ifndef RT_ASM_LOADS
 #define RT_ASM_LOADS 1  // node loads written in assembly (node_load); 0 = left to the compiler, 0.7 % slower
 #endif
-#ifndef RT_UNIFIED
-#define RT_UNIFIED 1  // megakernel: one kind of step for nodes and leaves (traverse_unified)
-#endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 8  // megakernel: waves per SIMD the register allocator must leave room for
 #endif
@@ -1141,8 +1138,12 @@ __device__ __forceinline__ void write_aux_tail(uint32_t *aux, size_t pix, const 
 // SAH, conservative 8-bit child boxes in 64-byte nodes (4 x 16-byte requests per visit instead of
 // 7, and 192 of them fit the workgroup's LDS copy instead of 109).  NOT the reference's tree, so
 // results differ where the reference's boxes or visiting order decide which hit is found.
-template <int MODE, bool AUX, bool STATS, bool FAST = false>
-__global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(TraceParams p) {
+// UNIFIED: nodes and leaves take the same kind of step (traverse_unified); otherwise a node step is
+// followed by the intersection of its leaves in steps of their own (node_step).  Which is faster
+// depends on the scene: the unified step saves load instructions, the separate steps run less
+// code per step (rt_api.cpp times both on the first frames of a scene and keeps the faster one).
+template <int MODE, bool AUX, bool STATS, bool FAST, bool UNIFIED>
+__device__ __forceinline__ void trace_body(const TraceParams &p) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_TRACE_BLOCK];
     uint32_t spill[RT_STACK_SPILL];
     const DevScene &sc = p.scene;
@@ -1177,12 +1178,9 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
                          : V(1.0f / ps.D.x, 1.0f / ps.D.y, 1.0f / ps.D.z);
             float best = 1e38f;
             uint32_t code = 0xFFFFFFFFu;
-#if RT_UNIFIED
-            if (!FAST) {
+            if (UNIFIED && !FAST) {
                 traverse_unified<STATS, RT_TRACE_BLOCK, RT_STACK_LDS, TOP>(sc, ps.O, ps.D, ID, best, code, stack, spill, st, top);
-            } else
-#endif
-            {
+            } else {
                 int sp = 1;
                 stack[0] = 0u;
                 while (sp > 0)
@@ -1207,6 +1205,16 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(Tra
         }
     }
     flush_counters<STATS>(p.counters, lane, nrays, st);
+}
+
+template <int MODE, bool AUX, bool STATS, bool FAST = false>
+__global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_kernel(TraceParams p) {
+    trace_body<MODE, AUX, STATS, FAST, true>(p);
+}
+// the default tree with leaf steps of their own
+template <int MODE, bool AUX, bool STATS>
+__global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_leafstep_kernel(TraceParams p) {
+    trace_body<MODE, AUX, STATS, false, false>(p);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1424,13 +1432,17 @@ void launch_trace_fast(const TraceParams &p, int mode, bool aux, bool stats, hip
 #undef L
 }
 
-void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s) {
+void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, bool leaf_steps, hipStream_t s) {
     if (p.ntiles == 0) return;  // image smaller than one dispatch group: the reference dispatches nothing
     // 8 equal runs of workgroups, one per XCD; surplus workgroups exit at once
     const uint32_t mx = (p.tiles_x + RT_MACRO - 1) / RT_MACRO, my = (p.tiles_y + RT_MACRO - 1) / RT_MACRO;
     const uint32_t groups = ((mx * my + 7u) / 8u) * 8u * (RT_MACRO * RT_MACRO * 4u) / RT_TRACE_WAVES;
     dim3 grid(groups), block(RT_TRACE_BLOCK);
-#define L(M, A, S) hipLaunchKernelGGL((trace_kernel<M, A, S>), grid, block, 0, s, p)
+#define L(M, A, S)                                                                                  \
+    do {                                                                                            \
+        if (leaf_steps) hipLaunchKernelGGL((trace_leafstep_kernel<M, A, S>), grid, block, 0, s, p); \
+        else hipLaunchKernelGGL((trace_kernel<M, A, S>), grid, block, 0, s, p);                     \
+    } while (0)
     if (mode == 0) {
         if (aux && stats) L(0, true, true);
         else if (aux) L(0, true, false);

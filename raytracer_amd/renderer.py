@@ -159,6 +159,13 @@ class Renderer:
 
     _fast = False
 
+    def traversal_variant(self) -> tuple[str, bool]:
+        """Which traversal variant the default pipeline uses for this scene ("unified" or
+        "leaf steps") and whether the timed frames that decide it have run."""
+        ls, dec = C.c_int(), C.c_int()
+        _lib.check(self._L.rt_traversal_variant(self._ctx, C.byref(ls), C.byref(dec)))
+        return ("leaf steps" if ls.value else "unified"), bool(dec.value)
+
     def fast_bvh(self) -> np.ndarray:
         """The fast-mode tree as built for the current scene: (n + 1, 16) uint32, the last node a sentinel."""
         nn = C.c_uint32()

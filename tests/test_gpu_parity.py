@@ -24,20 +24,24 @@ def _cases():
     return out
 
 
-@pytest.fixture(scope="module", params=["wave", "mega", "regroup"])
+@pytest.fixture(scope="module", params=["wave", "mega", "mega-leafsteps", "regroup"])
 def renderer(request):
-    """Every scheduling of the same arithmetic: the wavefront pipeline, the megakernel (default) and
-    the megakernel that regroups a tile's live rays while they traverse."""
+    """Every scheduling of the same arithmetic: the wavefront pipeline, the megakernel (default) in
+    both of its traversal variants (unified node / leaf step, leaf steps of their own) and the
+    megakernel that regroups a tile's live rays while they traverse."""
     import os
 
     from raytracer_amd.renderer import Renderer
 
-    os.environ["RT_PIPELINE"] = request.param
+    os.environ["RT_PIPELINE"] = request.param.split("-")[0]
+    if request.param.startswith("mega"):
+        os.environ["RT_LEAF_STEPS"] = "1" if request.param.endswith("leafsteps") else "0"
     try:
         r = Renderer(device=0, singleton=False)
     finally:
         os.environ.pop("RT_PIPELINE", None)
-    r.pipeline_name = request.param
+        os.environ.pop("RT_LEAF_STEPS", None)
+    r.pipeline_name = request.param.split("-")[0]
     yield r
     r.close()
 
@@ -482,3 +486,34 @@ def test_error_reporting(renderer):
         renderer.bounces = -1
     with pytest.raises(RuntimeError):
         renderer.render_sum(0, 1, shard=3, nshards=3)
+
+
+def test_traversal_variant_is_chosen_before_the_first_plain_frame_and_changes_no_pixel():
+    """Left to itself the library times both traversal variants before the first plain frame of a
+    scene and keeps one (rt_traversal_variant); the launches it does that with leave no trace in the
+    images or the counters, and whichever variant runs, the images are the reference shader's."""
+    from raytracer_amd.renderer import Renderer
+
+    scene, tag = _cases()[0]
+    rec = json.loads((GOLDEN / scene / f"{tag}.json").read_text())
+    hashes = rec["kinds"]["color"]["sha256_per_frame"] if "kinds" in rec else rec["sha256_per_frame"]
+    w, h, b = rec["w"], rec["h"], rec["bounces"]
+    f0, f1 = rec["frames"]
+    r = Renderer(device=0, singleton=False)
+    try:
+        load_golden_scene(r, scene)
+        assert r.traversal_variant()[1] is False
+        render_frame(r, w, h, f0, b, stats=True)  # an instrumented frame decides nothing
+        assert r.traversal_variant()[1] is False
+        rays_of_one_frame = r.stats()["rays"]
+        r.reset_stats()
+        r.set_flags(stats=False)
+        for f in range(f0, f1):
+            assert sha(render_frame(r, w, h, f, b)) == hashes[f - f0], f"frame {f}"
+        name, decided = r.traversal_variant()
+        assert decided and name in ("unified", "leaf steps")
+        assert r.stats()["rays"] == 0 or r.stats()["rays"] <= rays_of_one_frame * (f1 - f0) * 1.01
+        r.update_size(w + 8, h)  # a resize starts the timing again
+        assert r.traversal_variant()[1] is False
+    finally:
+        r.close()
