@@ -372,6 +372,7 @@ def worker(args):
         r.render_sum(first_frame=0, nframes=1)
         r.sync()
         r.clear_sum()
+        r.reset_stats()
         comm = D.Comm(r, rank, world, rehearse=rehearse)
         joined = comm.all_reduce([1.0], "sum")[0]
         if int(round(joined)) != args.gpus:
