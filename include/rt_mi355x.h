@@ -165,7 +165,8 @@ int rt_fast_bvh_export(rt_ctx *ctx, void *nodes, size_t nodes_bytes);
  * or leaf intersections in steps of their own -- and neither is faster on every scene.  Before the
  * first plain frame (no RT_FLAG_*) after a scene upload or a resize, rt_render / rt_render_sum
  * therefore time both with four extra launches that write no image and touch no counter the
- * caller sees (about four frame times, once per scene), and keep the faster.  *leaf_steps = the
+ * caller sees (about four frame times, once per scene; a scene uploaded again at about the same
+ * size, within a quarter in records and pixels, keeps the choice), and keep the faster.  *leaf_steps = the
  * variant in use (1 = leaf steps of their own), *decided = 0 until that has happened.
  * RT_LEAF_STEPS=0 / 1 in the environment at rt_create fixes the variant and skips the timing.
  */

@@ -133,6 +133,9 @@ struct rt_ctx {
     float tune_ms[4] = {0.f, 0.f, 0.f, 0.f};
     hipEvent_t ev_tune[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     rt::Counters *tune_counters = nullptr;  // where those launches count their rays
+    // what the last timing was done on: a scene re-uploaded at about the same size (an animation)
+    // keeps the variant instead of paying four launches per upload
+    uint64_t tuned_records = 0, tuned_pixels = 0;
     uint32_t extend_waves = 8192;
     uint32_t refill_threshold = 16;
 };
@@ -414,6 +417,15 @@ uint64_t owned_pixels(int WW, int HH, uint32_t shard, uint32_t nshards) {
 // launches that write no image and count their rays apart.  Runs once, before the first plain frame.
 int choose_traversal_variant(rt_ctx *c, const rt::TraceParams &frame) {
     if (c->tuned || c->tune_fixed || c->pipeline != 0 || c->fast) return 0;
+    const uint64_t records = (uint64_t)c->nodes.count * 2u + c->tris.count + c->spheres.count;  // in 64-byte units
+    const uint64_t pixels = (uint64_t)c->W * (uint64_t)c->H;
+    auto near = [](uint64_t a, uint64_t b) { return a <= b + b / 4u && b <= a + a / 4u; };
+    if (c->tuned_records && near(records, c->tuned_records) && near(pixels, c->tuned_pixels)) {
+        c->tuned = true;
+        return 0;
+    }
+    c->tuned_records = records;
+    c->tuned_pixels = pixels;
     if (int rc = join(c)) return rc;
     c->main_dirty = true;
     rt::TraceParams q = frame;

@@ -516,7 +516,11 @@ def test_traversal_variant_is_chosen_before_the_first_plain_frame_and_changes_no
         name, decided = r.traversal_variant()
         assert decided and name in ("unified", "leaf steps")
         assert r.stats()["rays"] == 0 or r.stats()["rays"] <= rays_of_one_frame * (f1 - f0) * 1.01
-        r.update_size(w + 8, h)  # a resize starts the timing again
+        load_golden_scene(r, scene)  # the same scene uploaded again: undecided only until the next frame,
+        assert r.traversal_variant()[1] is False  # which keeps the choice without timing anything
+        assert sha(render_frame(r, w, h, f0, b)) == hashes[0]
+        assert r.traversal_variant() == (name, True)
+        r.update_size(w * 2, h * 2)  # a much larger image starts the timing again
         assert r.traversal_variant()[1] is False
     finally:
         r.close()
