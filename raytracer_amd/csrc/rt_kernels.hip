@@ -19,7 +19,7 @@ namespace rt {
                            // 20 KB a workgroup may use while 8 of them share a CU; 0 = none
 #endif
 #ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES 4   // megakernel: wavefronts per workgroup (each an 8x8 quarter of a 16x16 tile); 1, 2, 4 or 8
+#define RT_TRACE_WAVES 4   // megakernel: wavefronts per workgroup, each an 8x8 quarter of a 16x16 tile (the regrouping kernel assumes 4)
 #endif
 #define RT_TRACE_BLOCK (64 * RT_TRACE_WAVES)
 #ifndef RT_TOP_STRIDE
@@ -34,9 +34,6 @@ namespace rt {
 #endif
 #ifndef RT_STACK_SPILL
 #define RT_STACK_SPILL 56
-#endif
-#ifndef RT_ASM_LOADS
-#define RT_ASM_LOADS 1  // node loads written in assembly (node_load); 0 = left to the compiler, 0.7 % slower
 #endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 8  // megakernel: waves per SIMD the register allocator must leave room for
@@ -439,7 +436,6 @@ __device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeR
         return;
     }
     ni = min(ni, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
-#if RT_ASM_LOADS
     if (TOP > 0) {
         // Written in assembly so that the two cases may be in flight together: in a wavefront whose
         // lanes split between them the compiler would wait for all global loads before it issues the
@@ -479,14 +475,7 @@ __device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeR
         nd.mt = make_float4(a6.x, a6.y, a6.z, a6.w);
         return;
     }
-#endif
-    if (TOP > 0 && ni < (uint32_t)TOP) {
-        LdsTop tp = top + ni * RT_TOP_STRIDE;
-        nd.lox = ld4(tp), nd.hix = ld4(tp + 1), nd.loy = ld4(tp + 2), nd.hiy = ld4(tp + 3), nd.loz = ld4(tp + 4),
-        nd.hiz = ld4(tp + 5), nd.mt = ld4(tp + 6);
-        return;
-    }
-    GlobalNodes np = (GlobalNodes)sc.nodes + (size_t)ni * kNodeVec;
+    GlobalNodes np = (GlobalNodes)sc.nodes + (size_t)ni * kNodeVec;  // no LDS copy: plain loads
     nd.lox = ld4(np), nd.hix = ld4(np + 1), nd.loy = ld4(np + 2), nd.hiy = ld4(np + 3), nd.loz = ld4(np + 4),
     nd.hiz = ld4(np + 5), nd.mt = ld4(np + 6);
 }
