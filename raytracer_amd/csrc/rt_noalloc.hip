@@ -177,7 +177,9 @@ extern "C" int rt_render_noalloc(int device, const rt_scene_view *sv, int width,
     p.tiles_x = (uint32_t)((p.WW + 15) / 16);
     p.tiles_y = (uint32_t)((p.HH + 15) / 16);
     p.ntiles = p.tiles_x * p.tiles_y;
-    launch_trace(p, 0, false, false, false, s);
+    // scenes within this entry point's limits are cache-resident: the variant with leaf steps of
+    // their own is the faster one there (it cannot be timed here: that would need a host wait)
+    launch_trace(p, 0, false, false, true, s);
     if (acc_rgba)
         launch_accumulate(p.sample, reinterpret_cast<float4 *>(acc_rgba), (size_t)width * height,
                           (float)accumulated_frames, s);
