@@ -367,9 +367,9 @@ def worker(args):
         r.update_size(args.width, args.height)
         bufs.upload(r)
         r.bounces = args.bounces
-        # The library times its two traversal variants before the first plain frame of a scene
+        # The library times its two traversal variants once a scene is in use for more than a few frames
         # (rt_traversal_variant in the header) and keeps the faster: let that happen before any timing.
-        r.render_sum(first_frame=0, nframes=1)
+        r.render_sum(first_frame=0, nframes=8)
         r.sync()
         r.clear_sum()
         r.reset_stats()

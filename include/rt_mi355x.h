@@ -162,13 +162,14 @@ int rt_fast_bvh_export(rt_ctx *ctx, void *nodes, size_t nodes_bytes);
 /*
  * No counterpart in the reference (a scheduling detail of this library; results do not depend on
  * it).  The default pipeline has two traversal variants -- one kind of step for nodes and leaves,
- * or leaf intersections in steps of their own -- and neither is faster on every scene.  Before the
- * first plain frame (no RT_FLAG_*) after a scene upload or a resize, rt_render / rt_render_sum
- * therefore time both with four extra launches that write no image and touch no counter the
- * caller sees (about four frame times, once per scene; a scene uploaded again at about the same
- * size, within a quarter in records and pixels, keeps the choice), and keep the faster.  *leaf_steps = the
- * variant in use (1 = leaf steps of their own), *decided = 0 until that has happened.
- * RT_LEAF_STEPS=0 / 1 in the environment at rt_create fixes the variant and skips the timing.
+ * or leaf intersections in steps of their own -- and neither is faster on every scene.  Once a
+ * scene has seen four plain frames (no RT_FLAG_*), or before a call of eight or more, rt_render /
+ * rt_render_sum therefore time both with four extra launches that write no image and touch no
+ * counter the caller sees (about four frame times, once per scene; a scene uploaded again at about
+ * the same size, within a quarter in records and pixels, keeps the choice), and keep the faster.
+ * Until then the size of the scene decides.  *leaf_steps = the variant in use (1 = leaf steps of
+ * their own), *decided = 0 until the timing has happened.  RT_LEAF_STEPS=0 / 1 in the environment
+ * at rt_create fixes the variant and skips the timing.
  */
 int rt_traversal_variant(rt_ctx *ctx, int *leaf_steps, int *decided);
 

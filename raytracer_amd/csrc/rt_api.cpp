@@ -136,6 +136,7 @@ struct rt_ctx {
     // what the last timing was done on: a scene re-uploaded at about the same size (an animation)
     // keeps the variant instead of paying four launches per upload
     uint64_t tuned_records = 0, tuned_pixels = 0;
+    uint32_t plain_frames = 0;  // plain frames rendered since the scene or the size changed, while undecided
     uint32_t extend_waves = 8192;
     uint32_t refill_threshold = 16;
 };
@@ -414,14 +415,22 @@ uint64_t owned_pixels(int WW, int HH, uint32_t shard, uint32_t nshards) {
 }
 
 // Times the two traversal variants on this scene, image size and shard (see rt_ctx::leaf_steps) with
-// launches that write no image and count their rays apart.  Runs once, before the first plain frame.
-int choose_traversal_variant(rt_ctx *c, const rt::TraceParams &frame) {
+// launches that write no image and count their rays apart.  Called before the plain frames of a
+// call (`frames` of them); runs once per scene, and not before the scene has seen a few frames or a
+// long call: a one-frame job should not pay four launches for its one.  Until then the size of the
+// scene decides (cache-resident scenes do better with leaf steps of their own).
+int choose_traversal_variant(rt_ctx *c, const rt::TraceParams &frame, uint32_t frames) {
     if (c->tuned || c->tune_fixed || c->pipeline != 0 || c->fast) return 0;
     const uint64_t records = (uint64_t)c->nodes.count * 2u + c->tris.count + c->spheres.count;  // in 64-byte units
     const uint64_t pixels = (uint64_t)c->W * (uint64_t)c->H;
     auto near = [](uint64_t a, uint64_t b) { return a <= b + b / 4u && b <= a + a / 4u; };
     if (c->tuned_records && near(records, c->tuned_records) && near(pixels, c->tuned_pixels)) {
         c->tuned = true;
+        return 0;
+    }
+    if (c->plain_frames < 4u && frames < 8u) {
+        c->leaf_steps = records < 100000u ? 1 : 0;
+        c->plain_frames += frames;
         return 0;
     }
     c->tuned_records = records;
@@ -589,7 +598,7 @@ int rt_resize(rt_ctx *c, int width, int height) {
     if ((size_t)width * (size_t)height > ((size_t)1 << 28)) return fail("rt_resize: image too large");
     HIP_TRY(hipSetDevice(c->device));
     if (int rc = sync_all(c)) return rc;
-    c->tuned = false;
+    c->tuned = false, c->plain_frames = 0;
     return alloc_images(c, width, height);
 }
 
@@ -612,7 +621,7 @@ int rt_upload(rt_ctx *c, int binding, const void *data, size_t nbytes) {
         // the caller's array may be reused as soon as this returns, as with glBufferData
         HIP_TRY(hipMemcpy(b->raw, data, nbytes, hipMemcpyHostToDevice));
     }
-    if (binding != RT_BINDING_MATERIALS) c->tuned = false;  // a new scene: time the variants again
+    if (binding != RT_BINDING_MATERIALS) c->tuned = false, c->plain_frames = 0;  // a new scene: time the variants again
     if (binding == RT_BINDING_BVH) c->host_nodes.assign((const uint32_t *)data, (const uint32_t *)data + nbytes / 4);
     if (binding == RT_BINDING_TRIANGLES || binding == RT_BINDING_SPHERES || binding == RT_BINDING_BOXES) {
         std::vector<uint32_t> &h = binding == RT_BINDING_TRIANGLES ? c->host_tris
@@ -658,7 +667,7 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounces, 
     p.aux = aux ? c->aux : nullptr;
     p.bounces = bounces;
     if (!aux && !stats && nframes)
-        if (int rc = choose_traversal_variant(c, p)) return rc;
+        if (int rc = choose_traversal_variant(c, p, nframes)) return rc;
     if (int rc = begin_timed(c)) return rc;
     for (uint32_t i = 0; i < nframes; i++) {
         p.time = (float)(first_frame + i);  // renderer.py:211 float(self._frames)
@@ -804,7 +813,7 @@ int rt_render_sum(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounc
     if (c->sum2_dirty && c->sum2_target != target)
         if (int rc = join(c)) return rc;
     if (frame_phase < nframes)
-        if (int rc = choose_traversal_variant(c, p)) return rc;
+        if (int rc = choose_traversal_variant(c, p, (nframes - frame_phase + frame_stride - 1u) / frame_stride)) return rc;
     if (int rc = begin_timed(c)) return rc;
     for (uint32_t i = frame_phase; i < nframes; i += frame_stride) {
         p.time = (float)(first_frame + i);

@@ -48,9 +48,17 @@ def run_mean(name, bufs, w, h, spp, bounces, golden_acc_hash=None):
     img = r.read_accumulation()
     t_read = time.perf_counter() - t2
     rays = r.stats()["rays"]
+    # steady state: the same frames once more, outside the run's own clock (the library's one-off
+    # timing of its traversal variants falls into the run above)
+    t3 = time.perf_counter()
+    if spp > 1:
+        r.render(frames=spp - 1)
+    r.sync()
+    t_steady = (time.perf_counter() - t3) / max(1, spp - 1)
     out = {"config": name, "size": [w, h], "spp": spp, "bounces": bounces, "rays": rays,
            "upload_plus_first_frame_ms": t_first * 1e3, "remaining_frames_ms": t_rest * 1e3,
-           "ms_per_frame_steady": t_rest / max(1, spp - 1) * 1e3, "readback_ms": t_read * 1e3,
+           "ms_per_frame_steady": t_steady * 1e3, "traversal_variant": r.traversal_variant()[0],
+           "readback_ms": t_read * 1e3,
            "Mrays_per_s_device": rays / (t_first + t_rest) / 1e6,
            "Mrays_per_s_with_pcie": rays / (t_first + t_rest + t_read) / 1e6}
     if golden_acc_hash:
