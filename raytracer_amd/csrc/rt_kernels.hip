@@ -1213,8 +1213,8 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_leafstep_k
 // its last ray is done.  Here the four wavefronts of a tile stop every RT_REGROUP_STEPS node steps;
 // if the rays still traversing would fit into fewer wavefronts, those of the emptiest wavefronts
 // ("donors") move into idle lanes of the fullest ones ("keepers") and the donors fall silent for
-// the rest of the bounce.  What moves is origin, direction, best hit and stack height (through a
-// 2 KB LDS buffer); the LDS stack column stays where it is and is addressed by the ray's home
+// the rest of the bounce.  What moves is origin, direction, best hit and where the ray stands in
+// its traversal (next item, pending leaves, stack height: 64 bytes per ray through a 4 KB LDS buffer); the LDS stack column stays where it is and is addressed by the ray's home
 // thread, the part of a stack that has overflowed into private memory cannot move, so a wavefront
 // holding such a ray is always a keeper.  A ray's own sequence of node visits and intersection
 // tests is untouched: results are those of trace_kernel bit for bit.  Hit distance and primitive
@@ -1224,14 +1224,14 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK, RT_MIN_WAVES) void trace_leafstep_k
 #ifndef RT_REGROUP_STEPS
 #define RT_REGROUP_STEPS 8
 #endif
-#define RT_RG_TOP 85  // leading nodes in LDS: what is left of 20 KB next to the stack and the transfer buffer
+#define RT_RG_TOP 69  // leading nodes in LDS: what is left of 20 KB next to the stack and the transfer buffer
 
 template <int MODE, bool AUX, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_regroup_kernel(TraceParams p) {
     __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
     __shared__ float4 lds_top[RT_RG_TOP * RT_TOP_STRIDE];
-    __shared__ float4 xfer[2 * 64];              // a moving ray: O.xyz best | D.xyz primitive
-    __shared__ uint32_t xmeta[64];               //   its stack height | home thread << 8
+    __shared__ float4 xfer[4 * 64];              // a moving ray: O.xyz best | D.xyz primitive | its next item, three pending
+                                                 // leaves | the fourth, the pending mask, stack height, home thread
     __shared__ uint32_t xvisits[STATS ? 64 : 1];  //   node visits of this ray so far (instrumented builds)
     __shared__ unsigned long long rg_mask[2][4];  // per round parity and wavefront: lanes with a ray still traversing
     __shared__ uint32_t rg_pin[2][4];             //   the wavefront holds a ray whose stack reaches into private memory
@@ -1260,30 +1260,31 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_regroup_kernel(T
         v3 ID = V(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
         float best = 1e38f;
         uint32_t code = 0xFFFFFFFFu, slot = threadIdx.x, visits = 0;
-        int sp = path_alive ? 1 : 0;
+        Walk w;
+        w.cur = 0u, w.ll = {0u, 0u, 0u, 0u, 0}, w.sp = 0, w.have = false;
         bool has = path_alive;
-        if (has) lds_stack[slot] = 0u;
+        if (has) walk_begin<STATS>(w, st);
         // bit 1 of what a wavefront publishes next to its mask: some path of it was alive at this bounce
         const uint32_t wave_has_paths = __ballot(path_alive) != 0ull ? 2u : 0u;
         bool any_path = true;
         for (;; round++) {
             for (int k = 0; k < RT_REGROUP_STEPS; k++) {
-                if (__ballot(sp > 0) == 0ull) break;
-                if (sp > 0) {
+                if (__ballot(w.have) == 0ull) break;
+                if (w.have) {
                     const uint32_t before = st.nodes;
-                    node_step<STATS, RT_BLOCK, RT_STACK_LDS, RT_RG_TOP>(sc, O, D, ID, best, code, sp, lds_stack + slot, spill, st, top);
+                    walk_step<STATS, RT_BLOCK, RT_STACK_LDS, RT_RG_TOP>(sc, O, D, ID, best, code, w, lds_stack + slot, spill, st, top);
                     if (STATS) visits += st.nodes - before;
                 }
             }
             // a finished ray leaves its result in its home column
-            if (has && sp == 0) {
+            if (has && !w.have) {
                 lds_stack[slot] = f2u(best);
                 lds_stack[RT_BLOCK + slot] = code;
                 if (STATS) lds_stack[2 * RT_BLOCK + slot] = visits;
                 has = false;
             }
             const unsigned long long mine = __ballot(has);
-            const bool pinned = __ballot(has && sp > RT_STACK_LDS) != 0ull;
+            const bool pinned = __ballot(has && w.sp > RT_STACK_LDS) != 0ull;
             const uint32_t par = round & 1u;
             if (lane == 0) {
                 rg_mask[par][wave] = mine;
@@ -1334,23 +1335,25 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_regroup_kernel(T
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
             if (!keeper && has) {
                 const uint32_t m = mover_base + below;
-                xfer[2 * m] = make_float4(O.x, O.y, O.z, best);
-                xfer[2 * m + 1] = make_float4(D.x, D.y, D.z, u2f(code));
-                xmeta[m] = (uint32_t)sp | (slot << 8);
+                xfer[4 * m] = make_float4(O.x, O.y, O.z, best);
+                xfer[4 * m + 1] = make_float4(D.x, D.y, D.z, u2f(code));
+                xfer[4 * m + 2] = make_float4(u2f(w.cur), u2f(w.ll.l0), u2f(w.ll.l1), u2f(w.ll.l2));
+                xfer[4 * m + 3] = make_float4(u2f(w.ll.l3), u2f((uint32_t)w.ll.n), u2f((uint32_t)w.sp), u2f(slot));
                 if (STATS) xvisits[m] = visits;
                 has = false;
-                sp = 0;
+                w.have = false;
             }
             __syncthreads();
             if (keeper && !has) {
                 const uint32_t h = hole_base + (lane - below);
                 if (h < movers) {
-                    const float4 a = xfer[2 * h], b = xfer[2 * h + 1];
-                    const uint32_t mt = xmeta[h];
+                    const float4 a = xfer[4 * h], b = xfer[4 * h + 1], c2 = xfer[4 * h + 2], d2 = xfer[4 * h + 3];
                     O = V(a.x, a.y, a.z), D = V(b.x, b.y, b.z);
                     ID = V(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
                     best = a.w, code = f2u(b.w);
-                    sp = (int)(mt & 0xFFu), slot = mt >> 8;
+                    w.cur = f2u(c2.x), w.ll.l0 = f2u(c2.y), w.ll.l1 = f2u(c2.z), w.ll.l2 = f2u(c2.w);
+                    w.ll.l3 = f2u(d2.x), w.ll.n = (int)f2u(d2.y), w.sp = (int)f2u(d2.z), slot = f2u(d2.w);
+                    w.have = true;
                     if (STATS) visits = xvisits[h];
                     has = true;
                 }
