@@ -124,10 +124,11 @@ struct rt_ctx {
     int comm_rank = 0, comm_world = 1;
     double *comm_scratch = nullptr;
     // Traversal variant of the megakernel (rt_kernels.hip, trace_body): the unified node / leaf step
-    // or leaf steps of their own.  Neither wins everywhere, so before the first plain frame of a
-    // scene four extra launches that write nothing are timed -- leaf steps, unified (both to get the
-    // kernels loaded and the caches warm), then leaf steps and unified again -- and the faster of
-    // the last two is kept until the scene or the image size changes.  RT_LEAF_STEPS=0 / 1 fixes it.
+    // or leaf steps of their own.  Neither wins everywhere.  A new scene starts on the variant its
+    // size suggests; once it has rendered a few plain frames (or one long call arrives), four extra
+    // launches that write nothing are timed -- leaf steps, unified (both to get the kernels loaded
+    // and the caches warm), then leaf steps and unified again -- and the faster of the last two is
+    // kept until the scene or the image size changes.  RT_LEAF_STEPS=0 / 1 fixes it.
     int leaf_steps = 0;
     bool tuned = false, tune_fixed = false;
     float tune_ms[4] = {0.f, 0.f, 0.f, 0.f};
@@ -287,8 +288,9 @@ int repack(rt_ctx *c, int binding) {
     // + 8: the traversal fetches records by the 128-byte line, so the line of the last record must be readable
     size_t need = ((size_t)b->count + 1) * vecs_per_elem(binding) + 8;
     if (need > b->packed_cap) {
-        if (b->packed) HIP_TRY(hipFree(b->packed));
-        b->packed = nullptr;
+        float4 *old = b->packed;
+        b->packed = nullptr, b->packed_cap = 0;  // a failure below leaves "no records", not a stale capacity
+        if (old) HIP_TRY(hipFree(old));
         HIP_TRY(hipMalloc((void **)&b->packed, need * sizeof(float4)));
         b->packed_cap = need;
     }
@@ -297,9 +299,10 @@ int repack(rt_ctx *c, int binding) {
             std::vector<uint32_t> order, rank;
             breadth_first_order(c->host_nodes.data(), b->count, order, rank);
             if ((size_t)b->count + 1 > c->node_perm_cap) {
-                if (c->node_order) HIP_TRY(hipFree(c->node_order));
-                if (c->node_rank) HIP_TRY(hipFree(c->node_rank));
-                c->node_order = c->node_rank = nullptr;
+                uint32_t *old_order = c->node_order, *old_rank = c->node_rank;
+                c->node_order = c->node_rank = nullptr, c->node_perm_cap = 0;
+                if (old_order) HIP_TRY(hipFree(old_order));
+                if (old_rank) HIP_TRY(hipFree(old_rank));
                 HIP_TRY(hipMalloc((void **)&c->node_order, ((size_t)b->count + 1) * sizeof(uint32_t)));
                 HIP_TRY(hipMalloc((void **)&c->node_rank, ((size_t)b->count + 1) * sizeof(uint32_t)));
                 c->node_perm_cap = (size_t)b->count + 1;
@@ -612,24 +615,36 @@ int rt_upload(rt_ctx *c, int binding, const void *data, size_t nbytes) {
     if (nbytes / (size_t)stride >= ((size_t)1 << 30)) return fail("rt_upload: too many elements");
     HIP_TRY(hipSetDevice(c->device));
     if (int rc = sync_all(c)) return rc;  // the old buffer may still be in use
-    if (b->raw) HIP_TRY(hipFree(b->raw));
+    // From here until the copy has succeeded the binding is empty (and its host mirrors with it), so
+    // that a failed upload leaves a scene without these elements rather than counts that no longer
+    // match the device records.
+    uint32_t *old_raw = b->raw;
     b->raw = nullptr;
-    b->raw_bytes = nbytes;
-    b->count = (uint32_t)(nbytes / (size_t)stride);
-    if (nbytes) {
-        HIP_TRY(hipMalloc((void **)&b->raw, nbytes));
-        // the caller's array may be reused as soon as this returns, as with glBufferData
-        HIP_TRY(hipMemcpy(b->raw, data, nbytes, hipMemcpyHostToDevice));
-    }
-    if (binding != RT_BINDING_MATERIALS) c->tuned = false, c->plain_frames = 0;  // a new scene: time the variants again
-    if (binding == RT_BINDING_BVH) c->host_nodes.assign((const uint32_t *)data, (const uint32_t *)data + nbytes / 4);
-    if (binding == RT_BINDING_TRIANGLES || binding == RT_BINDING_SPHERES || binding == RT_BINDING_BOXES) {
-        std::vector<uint32_t> &h = binding == RT_BINDING_TRIANGLES ? c->host_tris
-                                   : binding == RT_BINDING_SPHERES ? c->host_spheres : c->host_boxes;
-        h.assign((const uint32_t *)data, (const uint32_t *)data + nbytes / 4);
-        c->fast_dirty = true;
-    }
+    b->raw_bytes = 0;
+    b->count = 0;
     b->dirty = true;
+    if (binding != RT_BINDING_MATERIALS) c->tuned = false, c->plain_frames = 0;  // a new scene: time the variants again
+    std::vector<uint32_t> *mirror = binding == RT_BINDING_BVH         ? &c->host_nodes
+                                    : binding == RT_BINDING_TRIANGLES ? &c->host_tris
+                                    : binding == RT_BINDING_SPHERES   ? &c->host_spheres
+                                    : binding == RT_BINDING_BOXES     ? &c->host_boxes : nullptr;
+    if (mirror) mirror->clear();
+    if (mirror && binding != RT_BINDING_BVH) c->fast_dirty = true;
+    if (old_raw) HIP_TRY(hipFree(old_raw));
+    if (nbytes) {
+        uint32_t *raw = nullptr;
+        HIP_TRY(hipMalloc((void **)&raw, nbytes));
+        // the caller's array may be reused as soon as this returns, as with glBufferData
+        hipError_t e = hipMemcpy(raw, data, nbytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(raw);
+            return fail(std::string("rt_upload: copy to the device: ") + hipGetErrorString(e));
+        }
+        if (mirror) mirror->assign((const uint32_t *)data, (const uint32_t *)data + nbytes / 4);
+        b->raw = raw;
+        b->raw_bytes = nbytes;
+        b->count = (uint32_t)(nbytes / (size_t)stride);
+    }
     return 0;
 }
 
