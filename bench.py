@@ -150,7 +150,7 @@ def run_c4(args, r, comm, rank, world, name, bufs, build_s, rehearse):
     """1080p frames: `rt_render` at one GPU, spp-sharded `rt_render_sum` + one reduce at N GPUs."""
     from raytracer_amd.camera import Camera
 
-    variant, _ = r.traversal_variant()   # chosen by the library on the first frames of this scene
+    variant, _ = r.traversal_variant()   # timed by the library during the settle step
     npix = args.width * args.height
     # per-ray work of this workload, from one untimed instrumented frame (counter kernel variant)
     r.set_flags(stats=True)
@@ -367,9 +367,9 @@ def worker(args):
         r.update_size(args.width, args.height)
         bufs.upload(r)
         r.bounces = args.bounces
-        # The library times its two traversal variants once a scene is in use for more than a few frames
+        # The library times its two traversal variants once a scene has rendered 64 frames
         # (rt_traversal_variant in the header) and keeps the faster: let that happen before any timing.
-        r.render_sum(first_frame=0, nframes=8)
+        r.render_sum(first_frame=0, nframes=64)
         r.sync()
         r.clear_sum()
         r.reset_stats()

@@ -125,7 +125,8 @@ struct rt_ctx {
     double *comm_scratch = nullptr;
     // Traversal variant of the megakernel (rt_kernels.hip, trace_body): the unified node / leaf step
     // or leaf steps of their own.  Neither wins everywhere.  A new scene starts on the variant its
-    // size suggests; once it has rendered a few plain frames (or one long call arrives), four extra
+    // size suggests; once it has rendered kTuneAfterFrames plain frames (or one call of that many
+    // arrives: the timing costs about four frames and wins 6 to 18 % of one), four extra
     // launches that write nothing are timed -- leaf steps, unified (both to get the kernels loaded
     // and the caches warm), then leaf steps and unified again -- and the faster of the last two is
     // kept until the scene or the image size changes.  RT_LEAF_STEPS=0 / 1 fixes it.
@@ -419,9 +420,11 @@ uint64_t owned_pixels(int WW, int HH, uint32_t shard, uint32_t nshards) {
 
 // Times the two traversal variants on this scene, image size and shard (see rt_ctx::leaf_steps) with
 // launches that write no image and count their rays apart.  Called before the plain frames of a
-// call (`frames` of them); runs once per scene, and not before the scene has seen a few frames or a
-// long call: a one-frame job should not pay four launches for its one.  Until then the size of the
+// call (`frames` of them); runs once per scene, and not before the scene has rendered
+// kTuneAfterFrames frames or a call of that many arrives: the four launches cost about four frames
+// and the better variant wins 6 to 18 % of a frame, so a short job never earns them back.  Until then the size of the
 // scene decides (cache-resident scenes do better with leaf steps of their own).
+constexpr uint32_t kTuneAfterFrames = 64;
 int choose_traversal_variant(rt_ctx *c, const rt::TraceParams &frame, uint32_t frames) {
     if (c->tuned || c->tune_fixed || c->pipeline != 0 || c->fast) return 0;
     const uint64_t records = (uint64_t)c->nodes.count * 2u + c->tris.count + c->spheres.count;  // in 64-byte units
@@ -431,7 +434,7 @@ int choose_traversal_variant(rt_ctx *c, const rt::TraceParams &frame, uint32_t f
         c->tuned = true;
         return 0;
     }
-    if (c->plain_frames < 4u && frames < 8u) {
+    if (c->plain_frames < kTuneAfterFrames && frames < kTuneAfterFrames) {
         c->leaf_steps = records < 100000u ? 1 : 0;
         c->plain_frames += frames;
         return 0;

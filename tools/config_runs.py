@@ -48,8 +48,10 @@ def run_mean(name, bufs, w, h, spp, bounces, golden_acc_hash=None):
     img = r.read_accumulation()
     t_read = time.perf_counter() - t2
     rays = r.stats()["rays"]
-    # steady state: the same frames once more, outside the run's own clock (the library's one-off
-    # timing of its traversal variants falls into the run above)
+    # steady state: the same frames once more, outside the run's own clock and after a batch long
+    # enough for the library to have timed its traversal variants on this scene (64 frames)
+    r.render(frames=64)
+    r.sync()
     t3 = time.perf_counter()
     if spp > 1:
         r.render(frames=spp - 1)
