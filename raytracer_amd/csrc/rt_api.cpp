@@ -615,7 +615,9 @@ int rt_upload(rt_ctx *c, int binding, const void *data, size_t nbytes) {
     if (nbytes && !data) return fail("rt_upload: null data");
     int stride = stride_of(binding);
     if (nbytes % (size_t)stride) return fail("rt_upload: size is not a multiple of the element stride");
-    if (nbytes / (size_t)stride >= ((size_t)1 << 30)) return fail("rt_upload: too many elements");
+    // 30-bit indices; for nodes the index one past the array (the sentinel) must be below 0x3FFFFFFF too
+    if (nbytes / (size_t)stride >= ((size_t)1 << 30) - (binding == RT_BINDING_BVH ? 1u : 0u))
+        return fail("rt_upload: too many elements");
     HIP_TRY(hipSetDevice(c->device));
     if (int rc = sync_all(c)) return rc;  // the old buffer may still be in use
     // From here until the copy has succeeded the binding is empty (and its host mirrors with it), so

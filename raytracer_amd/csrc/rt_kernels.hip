@@ -197,7 +197,9 @@ __global__ void repack_nodes_kernel(const uint32_t *__restrict__ src, uint32_t n
 #pragma unroll
     for (int k = 12; k < 16; k++) {
         const uint32_t idx = w[k] & 0x3FFFFFFFu;
-        if ((w[k] >> 30) == 3u && idx < n && rank) w[k] = 0xC0000000u | rank[idx];
+        // a node index beyond the array (the reference's empty slot is 0x3FFFFFFF) means the all-zero
+        // sentinel node n, as the traversal's own clamp would have it; no word is 0xFFFFFFFF afterwards
+        if ((w[k] >> 30) == 3u) w[k] = 0xC0000000u | (idx < n ? (rank ? rank[idx] : idx) : n);
     }
     const float mn[3] = {smin.x, smin.y, smin.z}, ex[3] = {sext.x, sext.y, sext.z};
     float lo[3][4], hi[3][4];
@@ -371,7 +373,7 @@ __device__ __forceinline__ bool box_distance(v3 O, v3 D, v3 b0, v3 b1, float &t_
     return true;
 }
 
-#define CSWAP(ka, kb, ma, mb, va, vb)  \
+#define CSWAP(ka, kb, ma, mb)          \
     {                                  \
         bool sw_ = (kb < ka);          \
         float tk_ = sw_ ? kb : ka;     \
@@ -380,9 +382,6 @@ __device__ __forceinline__ bool box_distance(v3 O, v3 D, v3 b0, v3 b1, float &t_
         uint32_t tm_ = sw_ ? mb : ma;  \
         mb = sw_ ? ma : mb;            \
         ma = tm_;                      \
-        uint32_t tv_ = sw_ ? vb : va;  \
-        vb = sw_ ? va : vb;            \
-        va = tv_;                      \
     }
 
 // One iteration of the reference's `while (stackPtr > 0)` loop: pop a node, slab-test its four
@@ -510,8 +509,12 @@ template <bool STATS, int STRIDE, int LDS_DEPTH, bool FAST = false>
 __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd, v3 O, v3 ID, float best, int &sp,
                                           uint32_t *stack, uint32_t *spill, LeafList &ll, LaneStats &st) {
     uint32_t m0 = f2u(nd.mt.x), m1 = f2u(nd.mt.y), m2 = f2u(nd.mt.z), m3 = f2u(nd.mt.w);
+    // A child that is not visited has its metadata word replaced by kSkip before the sort: the sort
+    // compares distances only, so the words travel exactly as before, with one word per child to
+    // move instead of two.  No child word equals kSkip by itself: the repack maps out-of-range node
+    // indices (the reference's empty slot, 0xFFFFFFFF) to the sentinel node, whose index is lower.
+    constexpr uint32_t kSkip = 0xFFFFFFFFu;
     float k0, k1, k2, k3;
-    uint32_t v0, v1, v2, v3_;  // 1 = the child is visited
     if (FAST) {
         const uint32_t ew = f2u(nd.lox.w);
         const float ax = u2f((ew & 0xFFu) << 23) * ID.x, ay = u2f(((ew >> 8) & 0xFFu) << 23) * ID.y,
@@ -519,7 +522,7 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
         const float bx = (nd.lox.x - O.x) * ID.x, by = (nd.lox.y - O.y) * ID.y, bz = (nd.lox.z - O.z) * ID.z;
         const uint32_t qlx = f2u(nd.hix.x), qhx = f2u(nd.hix.y), qly = f2u(nd.hix.z), qhy = f2u(nd.hix.w),
                        qlz = f2u(nd.loy.x), qhz = f2u(nd.loy.y);
-#define FSLAB(SH, M, KEY, VAL)                                                                             \
+#define FSLAB(SH, M, KEY)                                                                                  \
     {                                                                                                       \
         float t1x = __builtin_fmaf((float)((qlx >> SH) & 0xFFu), ax, bx), t2x = __builtin_fmaf((float)((qhx >> SH) & 0xFFu), ax, bx); \
         float t1y = __builtin_fmaf((float)((qly >> SH) & 0xFFu), ay, by), t2y = __builtin_fmaf((float)((qhy >> SH) & 0xFFu), ay, by); \
@@ -527,14 +530,14 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
         float tN = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));            \
         float tF = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z)) * 1.0000004f;            \
         KEY = tN;                                                                                           \
-        VAL = ((tN <= tF) && (tN < best) && (M != 0xFFFFFFFFu)) ? 1u : 0u;                                  \
+        M = ((tN <= tF) && (tN < best)) ? M : kSkip; /* an empty slot is kSkip already */                   \
     }
-        FSLAB(0, m0, k0, v0) FSLAB(8, m1, k1, v1) FSLAB(16, m2, k2, v2) FSLAB(24, m3, k3, v3_)
+        FSLAB(0, m0, k0) FSLAB(8, m1, k1) FSLAB(16, m2, k2) FSLAB(24, m3, k3)
 #undef FSLAB
     } else {
     float4 lox = nd.lox, hix = nd.hix, loy = nd.loy, hiy = nd.hiy, loz = nd.loz, hiz = nd.hiz;
     // compute.glsl:186-208, one child per macro expansion
-#define SLAB(c, KEY, VAL)                                                                        \
+#define SLAB(c, KEY, M)                                                                          \
     {                                                                                            \
         float t1x = (lox.c - O.x) * ID.x, t2x = (hix.c - O.x) * ID.x;                            \
         float t1y = (loy.c - O.y) * ID.y, t2y = (hiy.c - O.y) * ID.y;                            \
@@ -542,24 +545,25 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
         float tN = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f)); \
         float tF = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));              \
         KEY = tN;                                                                                \
-        VAL = ((tN <= tF) && (tN < best)) ? 1u : 0u;                                             \
+        M = ((tN <= tF) && (tN < best)) ? M : kSkip;                                             \
     }
-    SLAB(x, k0, v0) SLAB(y, k1, v1) SLAB(z, k2, v2) SLAB(w, k3, v3_)
+    SLAB(x, k0, m0) SLAB(y, k1, m1) SLAB(z, k2, m2) SLAB(w, k3, m3)
 #undef SLAB
     }
     // compute.glsl:210-223
-    CSWAP(k0, k1, m0, m1, v0, v1)
-    CSWAP(k2, k3, m2, m3, v2, v3_)
-    CSWAP(k0, k2, m0, m2, v0, v2)
-    CSWAP(k1, k3, m1, m3, v1, v3_)
-    CSWAP(k1, k2, m1, m2, v1, v2)
+    CSWAP(k0, k1, m0, m1)
+    CSWAP(k2, k3, m2, m3)
+    CSWAP(k0, k2, m0, m2)
+    CSWAP(k1, k3, m1, m3)
+    CSWAP(k1, k2, m1, m2)
     // compute.glsl:290-326: children are visited far to near; an inner child is pushed, a leaf is
     // intersected at once.  Pushing and intersecting do not influence each other, so the visit is
     // split in two passes that keep each kind in the reference's order: first the pushes
     // (k = 3..0), then the leaves (k = 3..0) from a per-lane list.  The wavefront then runs the
     // intersection code once per list position instead of once per child slot.
-    const uint32_t in3 = (m3 >= 0xC0000000u) ? v3_ : 0u, in2 = (m2 >= 0xC0000000u) ? v2 : 0u;
-    const uint32_t in1 = (m1 >= 0xC0000000u) ? v1 : 0u, in0 = (m0 >= 0xC0000000u) ? v0 : 0u;
+    // inner and visited: a node word other than kSkip
+    const uint32_t in3 = (m3 - 0xC0000000u < 0x3FFFFFFFu) ? 1u : 0u, in2 = (m2 - 0xC0000000u < 0x3FFFFFFFu) ? 1u : 0u;
+    const uint32_t in1 = (m1 - 0xC0000000u < 0x3FFFFFFFu) ? 1u : 0u, in0 = (m0 - 0xC0000000u < 0x3FFFFFFFu) ? 1u : 0u;
     if (sp + 4 <= LDS_DEPTH) {
         // all four candidate rows are in LDS: every child is stored at the running top and only
         // an inner, visited child advances it, so a skipped child is overwritten by the next one
@@ -592,17 +596,18 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
     }
     // build the list by prepending in the order k = 0..3, so that k = 3 ends up in front
     uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
-#define ADD_LEAF(VAL, IN, META)                                                                   \
+    int nl = 0;
+#define ADD_LEAF(META)                                                                            \
     {                                                                                             \
-        bool lf = VAL != IN;                                                                      \
+        bool lf = META < 0xC0000000u; /* a visited leaf */                                        \
+        nl += lf ? 1 : 0;                                                                         \
         l3 = lf ? l2 : l3;                                                                        \
         l2 = lf ? l1 : l2;                                                                        \
         l1 = lf ? l0 : l1;                                                                        \
         l0 = lf ? META : l0;                                                                      \
     }
-    ADD_LEAF(v0, in0, m0) ADD_LEAF(v1, in1, m1) ADD_LEAF(v2, in2, m2) ADD_LEAF(v3_, in3, m3)
+    ADD_LEAF(m0) ADD_LEAF(m1) ADD_LEAF(m2) ADD_LEAF(m3)
 #undef ADD_LEAF
-    const int nl = (int)((v0 + v1 + v2 + v3_) - (in0 + in1 + in2 + in3));
     ll.l0 = l0;
     ll.l1 = l1;
     ll.l2 = l2;
