@@ -94,6 +94,53 @@ def test_full_path_state_matches_oracle(renderer, scene, w, h, frame, bounces):
         assert np.array_equal(aux[..., k], raux[..., k]), f"aux word {k}"
 
 
+def test_child_words_that_point_outside_the_arrays(renderer):
+    """A tree whose child words name nodes and primitives beyond the arrays -- the reference's own
+    empty slot (0xFFFFFFFF: node 0x3FFFFFFF) given a real box, node indices just past the end, and
+    triangle indices past the end -- reads zero words there (GL robust buffer access, what llvmpipe
+    does); image, path state and counters must follow the oracle through all of it."""
+    d = GOLDEN / "gally"
+    bvh = np.fromfile(d / "bvh.bin", dtype=np.uint32).reshape(-1, 16).copy()
+    n_nodes = bvh.shape[0]
+    n_tris = (d / "tris.bin").stat().st_size // 64
+    rng = np.random.default_rng(7)
+    changed = {"empty": 0, "node": 0, "tri": 0}
+    for ni in rng.choice(n_nodes, size=min(400, n_nodes), replace=False):
+        k = int(rng.integers(4))
+        word = int(bvh[ni, 12 + k])
+        kind = int(rng.integers(3))
+        if word >> 30 == 3 and word != 0xFFFFFFFF and kind == 0:
+            bvh[ni, 12 + k] = 0xFFFFFFFF  # the box stays: rays that hit it push node 0x3FFFFFFF
+            changed["empty"] += 1
+        elif word >> 30 == 3 and word != 0xFFFFFFFF and kind == 1:
+            bvh[ni, 12 + k] = 0xC0000000 | (n_nodes + int(rng.integers(1, 9)))
+            changed["node"] += 1
+        elif word >> 30 == 0:
+            bvh[ni, 12 + k] = n_tris + int(rng.integers(0, 1000))
+            changed["tri"] += 1
+    assert all(v > 10 for v in changed.values()), changed
+    u = load_golden_scene(renderer, "gally")
+    renderer.update_ssbo(0, bvh.view(np.uint8).reshape(-1), 11)
+    sc = O.OracleScene(bvh=bvh.tobytes(), tris=(d / "tris.bin").read_bytes(), spheres=(d / "spheres.bin").read_bytes(),
+                       mats=(d / "mats.bin").read_bytes(), uniforms=u)
+    w, h, frame, bounces = 320, 180, 3, 4
+    renderer.reset_stats()
+    img = render_frame(renderer, w, h, frame, bounces, aux=True, stats=True)
+    aux = renderer.read_aux()
+    s = renderer.stats()
+    ref, raux, cnt = sc.render(w, h, frame, bounces, want_primary=True, want_counters=True)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    for k in range(16):
+        assert np.array_equal(aux[..., k], raux[..., k]), f"aux word {k}"
+    for k in ("rays", "nodes", "tri_tests", "sphere_tests", "max_stack"):
+        assert s[k] == cnt[k], k
+    plain = O.OracleScene.from_dir(d).render(w, h, frame, bounces)
+    assert not np.array_equal(plain, ref)  # the damage is visible: the test is not vacuous
+    # and without the instrumentation (the kernels the frame loop runs)
+    img2 = render_frame(renderer, w, h, frame, bounces)
+    assert np.array_equal(img2.view(np.uint32), ref.view(np.uint32))
+
+
 def test_counters_match_oracle(renderer):
     load_golden_scene(renderer, "gally")
     renderer.reset_stats()
