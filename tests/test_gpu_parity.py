@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from util import GOLDEN, load_golden_scene, render_frame, sha
+from util import GOLDEN, damaged_gally_bvh, load_golden_scene, render_frame, sha
 
 pytestmark = pytest.mark.gpu
 
@@ -97,27 +97,10 @@ def test_full_path_state_matches_oracle(renderer, scene, w, h, frame, bounces):
 def test_child_words_that_point_outside_the_arrays(renderer):
     """A tree whose child words name nodes and primitives beyond the arrays -- the reference's own
     empty slot (0xFFFFFFFF: node 0x3FFFFFFF) given a real box, node indices just past the end, and
-    triangle indices past the end -- reads zero words there (GL robust buffer access, what llvmpipe
-    does); image, path state and counters must follow the oracle through all of it."""
+    triangle indices past the end -- reads zero words there (GL robust buffer access); the image must be
+    the reference shader's own (llvmpipe, oracle/gen_out_of_range.py), path state and counters the oracle's."""
     d = GOLDEN / "gally"
-    bvh = np.fromfile(d / "bvh.bin", dtype=np.uint32).reshape(-1, 16).copy()
-    n_nodes = bvh.shape[0]
-    n_tris = (d / "tris.bin").stat().st_size // 64
-    rng = np.random.default_rng(7)
-    changed = {"empty": 0, "node": 0, "tri": 0}
-    for ni in rng.choice(n_nodes, size=min(400, n_nodes), replace=False):
-        k = int(rng.integers(4))
-        word = int(bvh[ni, 12 + k])
-        kind = int(rng.integers(3))
-        if word >> 30 == 3 and word != 0xFFFFFFFF and kind == 0:
-            bvh[ni, 12 + k] = 0xFFFFFFFF  # the box stays: rays that hit it push node 0x3FFFFFFF
-            changed["empty"] += 1
-        elif word >> 30 == 3 and word != 0xFFFFFFFF and kind == 1:
-            bvh[ni, 12 + k] = 0xC0000000 | (n_nodes + int(rng.integers(1, 9)))
-            changed["node"] += 1
-        elif word >> 30 == 0:
-            bvh[ni, 12 + k] = n_tris + int(rng.integers(0, 1000))
-            changed["tri"] += 1
+    bvh, changed = damaged_gally_bvh()
     assert all(v > 10 for v in changed.values()), changed
     u = load_golden_scene(renderer, "gally")
     renderer.update_ssbo(0, bvh.view(np.uint8).reshape(-1), 11)
@@ -130,6 +113,9 @@ def test_child_words_that_point_outside_the_arrays(renderer):
     s = renderer.stats()
     ref, raux, cnt = sc.render(w, h, frame, bounces, want_primary=True, want_counters=True)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    rec = json.loads((GOLDEN / "fuzz" / "damaged_gally.json").read_text())  # the reference shader on llvmpipe
+    assert sha(bvh) == rec["bvh_sha256"] and (w, h, bounces, frame) == (rec["w"], rec["h"], rec["bounces"], rec["frames"][0])
+    assert sha(img) == rec["kinds"]["color"]["sha256_per_frame"][0]
     for k in range(16):
         assert np.array_equal(aux[..., k], raux[..., k]), f"aux word {k}"
     for k in ("rays", "nodes", "tri_tests", "sphere_tests", "max_stack"):

@@ -217,3 +217,25 @@ def test_random_scenes_bit_exact():
                 code, tbits, exists = O.primary_from_golden(first["primary" + n])
                 assert np.array_equal(code, aux[..., 0]) and np.array_equal(tbits, aux[..., 1])
                 assert np.array_equal(exists, aux[..., 2])
+
+
+def test_child_words_outside_the_arrays_follow_the_reference_shader():
+    """The gally tree with child words that name nodes and triangles beyond the arrays (the
+    reference's empty-slot word on slots with a real box among them), rendered by the reference
+    shader on llvmpipe (oracle/gen_out_of_range.py): out-of-range reads deliver zero words, and the
+    restatement must agree bit for bit in the images and in the first hits."""
+    from util import damaged_gally_bvh
+
+    rec = json.loads((GOLDEN / "fuzz" / "damaged_gally.json").read_text())
+    bvh, changed = damaged_gally_bvh()
+    assert sha(bvh) == rec["bvh_sha256"] and changed == rec["changed_words"]
+    d = GOLDEN / "gally"
+    sc = O.OracleScene(bvh=bvh.tobytes(), tris=(d / "tris.bin").read_bytes(), spheres=(d / "spheres.bin").read_bytes(),
+                       mats=(d / "mats.bin").read_bytes(), uniforms=np.fromfile(d / "uniforms.bin", dtype=np.float32))
+    f0, f1 = rec["frames"]
+    for i, f in enumerate(range(f0, f1)):
+        img, aux = sc.render(rec["w"], rec["h"], f, rec["bounces"], want_primary=True)
+        assert sha(img) == rec["kinds"]["color"]["sha256_per_frame"][i], f"frame {f}"
+        if i == 0:
+            p = rec["primary_sha256_first_frame"]
+            assert sha(aux[..., 0]) == p["code"] and sha(aux[..., 1]) == p["t_bits"] and sha(aux[..., 2]) == p["exists"]

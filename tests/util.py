@@ -54,3 +54,29 @@ def fuzz_buffers(rec):
         assert sha(arr) == rec["buffers_sha256"][key], key
     u = np.array([int(x, 16) for x in rec["uniform_words"]], dtype=np.uint32).view(np.float32)
     return b, u
+
+
+def damaged_gally_bvh():
+    """The gally tree with child words that point outside the arrays: the reference's own empty-slot
+    word (0xFFFFFFFF = node 0x3FFFFFFF) on slots that keep a real box, node indices just past the
+    end, triangle indices past the end.  Returns (nodes as (n, 16) uint32, how many of each kind)."""
+    d = GOLDEN / "gally"
+    bvh = np.fromfile(d / "bvh.bin", dtype=np.uint32).reshape(-1, 16).copy()
+    n_nodes = bvh.shape[0]
+    n_tris = (d / "tris.bin").stat().st_size // 64
+    rng = np.random.default_rng(7)
+    changed = {"empty": 0, "node": 0, "tri": 0}
+    for ni in rng.choice(n_nodes, size=min(400, n_nodes), replace=False):
+        k = int(rng.integers(4))
+        word = int(bvh[ni, 12 + k])
+        kind = int(rng.integers(3))
+        if word >> 30 == 3 and word != 0xFFFFFFFF and kind == 0:
+            bvh[ni, 12 + k] = 0xFFFFFFFF  # the box stays: rays that hit it push node 0x3FFFFFFF
+            changed["empty"] += 1
+        elif word >> 30 == 3 and word != 0xFFFFFFFF and kind == 1:
+            bvh[ni, 12 + k] = 0xC0000000 | (n_nodes + int(rng.integers(1, 9)))
+            changed["node"] += 1
+        elif word >> 30 == 0:
+            bvh[ni, 12 + k] = n_tris + int(rng.integers(0, 1000))
+            changed["tri"] += 1
+    return bvh, changed
