@@ -888,7 +888,11 @@ struct Path {
 __device__ __forceinline__ void primary_ray(const DevScene &sc, int W, int H, int x, int y, float time, Path &ps) {
     float px = (float)(2 * x - W) / (float)W;
     float py = (float)(2 * y - H) / (float)H;
-    uint32_t state = ((uint32_t)x * 1973u + (uint32_t)y * 9277u + (uint32_t)(time * 1000.0f) * 26699u) | 1u;
+    // uint(time * 1000): beyond the range of uint (frame 4 294 968 on) the reference shader's
+    // conversion saturates, on llvmpipe as on GPUs; written out rather than left to the cast
+    const float ms = time * 1000.0f;
+    const uint32_t tw = ms >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)ms;
+    uint32_t state = ((uint32_t)x * 1973u + (uint32_t)y * 9277u + tw * 26699u) | 1u;
     float jx = draw(state) - 0.5f;
     float jy = draw(state) - 0.5f;
     float qx = px + jx / (float)W;

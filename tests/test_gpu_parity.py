@@ -127,6 +127,36 @@ def test_child_words_that_point_outside_the_arrays(renderer):
     assert np.array_equal(img2.view(np.uint32), ref.view(np.uint32))
 
 
+def test_material_indices_outside_the_array_and_uniforms_at_the_edges(renderer):
+    """Reference shader on llvmpipe (oracle/gen_out_of_range.py): material indices beyond the
+    material array read a zero material; fractional bounce counts, a count above the shader's own
+    depth cap, and frame numbers beyond 2^24 (float32 holds not every integer there, and from frame
+    4 294 968 on time * 1000 no longer fits a uint: the conversion saturates and all frames draw the
+    same samples)."""
+    from util import damaged_gally_materials
+
+    rec = json.loads((GOLDEN / "fuzz" / "damaged_materials.json").read_text())
+    tris, sph = damaged_gally_materials()
+    assert sha(tris) == rec["tris_sha256"] and sha(sph) == rec["spheres_sha256"]
+    load_golden_scene(renderer, "gally")
+    renderer.update_ssbo(0, tris.view(np.uint8).reshape(-1), 12)
+    renderer.update_ssbo(0, sph.view(np.uint8).reshape(-1), 5)
+    f0, f1 = rec["frames"]
+    for i, f in enumerate(range(f0, f1)):
+        assert sha(render_frame(renderer, rec["w"], rec["h"], f, rec["bounces"])) == rec["sha256_per_frame"][i], f
+    for run in json.loads((GOLDEN / "fuzz" / "edge_uniforms.json").read_text()):
+        load_golden_scene(renderer, run["scene"])
+        f0, f1 = run["frames"]
+        for i, f in enumerate(range(f0, f1)):
+            render_frame(renderer, run["w"], run["h"], f, 1)
+            # the uniform is a float and the C ABI takes it as one; the Python mirror, like the
+            # reference's property, only lets integers through, so the value goes in underneath it
+            renderer._bounces = run["bounces"]
+            renderer.set_frame_index(f)
+            renderer.render()
+            assert sha(renderer.read_sample()) == run["sha256_per_frame"][i], (run["scene"], run["bounces"], f)
+
+
 def test_counters_match_oracle(renderer):
     load_golden_scene(renderer, "gally")
     renderer.reset_stats()

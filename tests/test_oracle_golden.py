@@ -239,3 +239,30 @@ def test_child_words_outside_the_arrays_follow_the_reference_shader():
         if i == 0:
             p = rec["primary_sha256_first_frame"]
             assert sha(aux[..., 0]) == p["code"] and sha(aux[..., 1]) == p["t_bits"] and sha(aux[..., 2]) == p["exists"]
+
+
+def test_material_indices_outside_the_array_follow_the_reference_shader():
+    """Every seventh gally triangle and one sphere carry a material index beyond the material array;
+    the reference shader on llvmpipe reads a zero material there."""
+    from util import damaged_gally_materials
+
+    rec = json.loads((GOLDEN / "fuzz" / "damaged_materials.json").read_text())
+    tris, sph = damaged_gally_materials()
+    assert sha(tris) == rec["tris_sha256"] and sha(sph) == rec["spheres_sha256"]
+    d = GOLDEN / "gally"
+    sc = O.OracleScene(bvh=(d / "bvh.bin").read_bytes(), tris=tris.tobytes(), spheres=sph.tobytes(),
+                       mats=(d / "mats.bin").read_bytes(), uniforms=np.fromfile(d / "uniforms.bin", dtype=np.float32))
+    f0, f1 = rec["frames"]
+    for i, f in enumerate(range(f0, f1)):
+        assert sha(sc.render(rec["w"], rec["h"], f, rec["bounces"])) == rec["sha256_per_frame"][i], f"frame {f}"
+
+
+def test_uniforms_at_the_edges_follow_the_reference_shader(scenes):
+    """Fractional bounce counts, one above the shader's own depth cap, and frame numbers where
+    float32 no longer holds every integer (the shader's seed arithmetic is in float)."""
+    for run in json.loads((GOLDEN / "fuzz" / "edge_uniforms.json").read_text()):
+        sc = scenes(run["scene"])
+        f0, f1 = run["frames"]
+        for i, f in enumerate(range(f0, f1)):
+            img = sc.render(run["w"], run["h"], f, run["bounces"])
+            assert sha(img) == run["sha256_per_frame"][i], (run["scene"], run["bounces"], f)

@@ -80,3 +80,16 @@ def damaged_gally_bvh():
             bvh[ni, 12 + k] = n_tris + int(rng.integers(0, 1000))
             changed["tri"] += 1
     return bvh, changed
+
+
+def damaged_gally_materials():
+    """The gally triangles and spheres with material indices beyond the material array on every
+    seventh triangle and on the first sphere.  Returns (tris as (n, 16) uint32, spheres as (n, 8) uint32)."""
+    d = GOLDEN / "gally"
+    tris = np.fromfile(d / "tris.bin", dtype=np.uint32).reshape(-1, 16).copy()
+    sph = np.fromfile(d / "spheres.bin", dtype=np.uint32).reshape(-1, 8).copy()
+    n_mats = (d / "mats.bin").stat().st_size // 12
+    tris[::7, 3] = n_mats + (np.arange(tris[::7].shape[0], dtype=np.uint32) % 5)
+    if sph.shape[0]:
+        sph[0, 5] = 0x7FFFFFFF
+    return tris, sph
