@@ -92,7 +92,10 @@ int rt_set_camera(rt_ctx *ctx, const float inv_view_proj[16], const float eye[3]
  * rt_sync or any rt_read_* waits for it.  Consecutive frames overlap on the device (the compute
  * dispatch of frame k+1 may start while frame k drains; the accumulate passes run in frame order),
  * which changes no result; RT_OVERLAP=0 in the environment at rt_create keeps frames strictly
- * one after another, and frames with RT_FLAG_AUX always are. */
+ * one after another, and frames with RT_FLAG_AUX always are.  `bounces` is the float the uniform
+ * is (the shader traces uint(bounces) bounces, at most 64); a negative value or NaN, whose
+ * conversion GLSL leaves undefined and the reference's property setter never lets through
+ * (renderer.py:395-397), is an error. */
 int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t nframes, float bounces, uint32_t flags);
 
 /* Renderer.reset_accumulation (renderer.py:326-345): the accumulation image becomes a copy of the

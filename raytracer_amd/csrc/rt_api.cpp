@@ -670,6 +670,7 @@ int rt_set_camera(rt_ctx *c, const float m[16], const float eye[3]) {
 
 int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounces, uint32_t flags) {
     if (!c) return fail("rt_render: null context");
+    if (!(bounces >= 0.0f)) return fail("rt_render: bounces must not be negative");  // NaN included
     HIP_TRY(hipSetDevice(c->device));
     rt::TraceParams p;
     if (int rc = prepare_scene(c, &p.scene)) return rc;
@@ -817,6 +818,7 @@ int rt_render_sum(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounc
     if (!c) return fail("rt_render_sum: null context");
     if (nshards == 0 || shard >= nshards) return fail("rt_render_sum: shard must be < nshards");
     if (frame_stride == 0 || frame_phase >= frame_stride) return fail("rt_render_sum: frame_phase must be < frame_stride");
+    if (!(bounces >= 0.0f)) return fail("rt_render_sum: bounces must not be negative");
     HIP_TRY(hipSetDevice(c->device));
     rt::TraceParams p;
     if (int rc = prepare_scene(c, &p.scene)) return rc;

@@ -95,6 +95,7 @@ extern "C" int rt_render_noalloc(int device, const rt_scene_view *sv, int width,
     if (!sv) NA_FAIL("scene view is null");
     if (!sample_rgba) NA_FAIL("sample_rgba is null");
     if (width <= 0 || height <= 0) NA_FAIL("size must be positive");
+    if (!(bounces >= 0.0f)) NA_FAIL("bounces must not be negative");
     if ((size_t)width * (size_t)height > ((size_t)1 << 28)) NA_FAIL("image too large");
     if (device < 0 || device >= kMaxDevices) NA_FAIL("no such HIP device");
     struct {

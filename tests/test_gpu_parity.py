@@ -552,6 +552,14 @@ def test_error_reporting(renderer):
         renderer.bounces = -1
     with pytest.raises(RuntimeError):
         renderer.render_sum(0, 1, shard=3, nshards=3)
+    good = renderer._bounces
+    for bad in (-1.0, float("nan")):  # underneath the Python property: the C ABI refuses them itself
+        renderer._bounces = bad
+        with pytest.raises(RuntimeError, match="bounces"):
+            renderer.render()
+        with pytest.raises(RuntimeError, match="bounces"):
+            renderer.render_sum(0, 1)
+    renderer._bounces = good
 
 
 def test_traversal_variant_is_timed_once_a_scene_is_in_use_and_changes_no_pixel():
