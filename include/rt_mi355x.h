@@ -74,7 +74,11 @@ const char *rt_last_error(void);
 int rt_resize(rt_ctx *ctx, int width, int height);
 
 /* Renderer.update_ssbo (renderer.py:308-324): copies `nbytes` of host data into the buffer
- * for `binding`, replacing it wholesale.  The caller keeps ownership of `data`. */
+ * for `binding`, replacing it wholesale.  The caller keeps ownership of `data`.  `nbytes` must be a
+ * multiple of the binding's element size, and the element count must fit the 30-bit index of a
+ * BVH child word (below 2^30; below 2^30 - 1 for the BVH itself).  Child words and material
+ * indices that point beyond their arrays are legal and read zero words, as GL robust buffer
+ * access delivers them to the reference shader.  If the call fails, the binding is left empty. */
 int rt_upload(rt_ctx *ctx, int binding, const void *data, size_t nbytes);
 
 /* renderer.scene_min_coords / renderer.scene_extent (src/scene/scene.py:70-71), sent as the
