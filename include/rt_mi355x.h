@@ -172,12 +172,13 @@ int rt_fast_bvh_export(rt_ctx *ctx, void *nodes, size_t nodes_bytes);
  * or leaf intersections in steps of their own -- and neither is faster on every scene.  Once a
  * scene has seen 64 plain frames (no RT_FLAG_*), or before a call of 64 or more, rt_render /
  * rt_render_sum therefore time both with four extra launches that write no image and touch no
- * counter the caller sees (about four frame times, which the better variant's 6 to 18 % per frame earn back within a
- * hundred frames; once per scene; a scene uploaded again at about
- * the same size, within a quarter in records and pixels, keeps the choice), and keep the faster.
- * Until then the size of the scene decides.  *leaf_steps = the variant in use (1 = leaf steps of
- * their own), *decided = 0 until the timing has happened.  RT_LEAF_STEPS=0 / 1 in the environment
- * at rt_create fixes the variant and skips the timing.
+ * counter the caller sees, and keep the faster.  That costs about four frame times (less on
+ * images beyond 1080p, which are timed on every third or fourth 64x64 tile), which the better
+ * variant's 6 to 18 % per frame earn back within a hundred frames, and happens once per scene: a
+ * scene uploaded again at about the same size, within a quarter in records and pixels, keeps the
+ * choice.  Until then the size of the scene decides.  *leaf_steps = the variant in use (1 = leaf
+ * steps of their own), *decided = 0 until the timing has happened.  RT_LEAF_STEPS=0 / 1 in the
+ * environment at rt_create fixes the variant and skips the timing.
  */
 int rt_traversal_variant(rt_ctx *ctx, int *leaf_steps, int *decided);
 

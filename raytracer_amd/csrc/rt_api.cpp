@@ -449,6 +449,12 @@ int choose_traversal_variant(rt_ctx *c, const rt::TraceParams &frame, uint32_t f
     q.aux = nullptr;
     q.counters = c->tune_counters;
     q.time = 0.0f;
+    // a large unsharded image is timed on every k-th macro tile (the shard rule of rt_render_sum),
+    // as long as the tiles left still fill the chip several times over
+    if (q.nshards == 1u && q.ntiles >= 2u * 8160u) {
+        q.nshards = q.ntiles / 8160u < 4u ? q.ntiles / 8160u : 4u;
+        q.shard = 0u;
+    }
     for (int k = 0; k < 4; k++) {
         HIP_TRY(hipEventRecord(c->ev_tune[k], c->stream));
         rt::launch_trace(q, 0, false, false, (k & 1) == 0, c->stream);

@@ -1160,7 +1160,7 @@ __device__ __forceinline__ void trace_body(const TraceParams &p) {
     __syncthreads();
     LdsTop top = (LdsTop)lds_top;
     int x, y;
-    bool live = trace_pixel(p, MODE == 1, x, y);
+    bool live = trace_pixel(p, true, x, y);
     uint32_t lane = threadIdx.x & 63u;
     uint32_t *stack = lds_stack + threadIdx.x;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};
@@ -1253,7 +1253,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_regroup_kernel(T
     __syncthreads();
     LdsTop top = (LdsTop)lds_top;
     int x, y;
-    const bool live = trace_pixel(p, MODE == 1, x, y);
+    const bool live = trace_pixel(p, true, x, y);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0, path_visits = 0;
@@ -1473,7 +1473,7 @@ template <int MODE, bool AUX>
 __global__ __launch_bounds__(RT_BLOCK) void generate_kernel(TraceParams p, WaveQueues q) {
     const DevScene &sc = p.scene;
     int x, y;
-    bool live = tile_pixel(p, MODE == 1, x, y);
+    bool live = tile_pixel(p, true, x, y);
     const uint32_t nb = (uint32_t)p.bounces;
     // slot of this lane: its tile (after the XCD remap) times 256 plus its position in the tile
     const uint32_t per = (p.ntiles + 7u) / 8u;

@@ -85,8 +85,9 @@ def run_sum(name, bufs, w, h, spp, bounces):
     r.read_accumulation()
     t_read = time.perf_counter() - t2
     rays = r.stats()["rays"]
+    variant = r.traversal_variant()[0]
     r.close()
-    return {"config": name, "size": [w, h], "spp": spp, "bounces": bounces, "rays": rays,
+    return {"config": name, "size": [w, h], "spp": spp, "bounces": bounces, "rays": rays, "traversal_variant": variant,
             "upload_plus_render_ms": t_dev * 1e3, "readback_ms": t_read * 1e3,
             "Mrays_per_s_device": rays / t_dev / 1e6, "Mrays_per_s_with_pcie": rays / (t_dev + t_read) / 1e6}
 
