@@ -382,6 +382,30 @@ def main():
             cnt, _ = run_shader("counters", td, 1920, 1080, 4, 0, 1, T)
             rec["rays_frame0"] = int((cnt[0, :, :, 3].astype(np.int64) // 64).sum())
         (GOLD / "c4_sponza_synth_1920x1080_b4.json").write_text(json.dumps(rec, indent=1))
+    if args.only == "sponza4k":
+        # configuration C5's image size (3840x2160) on the same scene: two whole frames of the reference
+        # shader, hashes only (about a minute of llvmpipe per frame; not part of the default run)
+        from raytracer_amd import synth
+        from raytracer_amd import scene as S
+        scene, meshes = synth.sponza_synth(1.0)
+        b = S.build_scene(scene, extra_meshes=meshes, sequential_mesh_indices=True)
+        with tempfile.TemporaryDirectory(prefix="rtc5_") as td:
+            td = Path(td)
+            (td / "mats.bin").write_bytes(b.materials.tobytes())
+            (td / "spheres.bin").write_bytes(b.spheres.tobytes())
+            (td / "tris.bin").write_bytes(b.triangles.tobytes())
+            (td / "bvh.bin").write_bytes(b.bvh.tobytes())
+            inv_vp, eye = Camera().uniforms_f32()
+            np.concatenate([inv_vp, eye, b.scene_min, b.scene_extent]).astype(np.float32).tofile(td / "uniforms.bin")
+            rec = {"scene": "sponza_synth(detail=1.0), sequential mesh indices, default camera", "w": 3840, "h": 2160,
+                   "bounces": 4, "frames": [0, 2], "buffers_sha256": {"mats": sha(b.materials), "spheres": sha(b.spheres),
+                                                                     "tris": sha(b.triangles), "bvh": sha(b.bvh)}}
+            img, info = run_shader("color", td, 3840, 2160, 4, 0, 2, T)
+            rec["sample_sha256_per_frame"] = [sha(img[i]) for i in range(2)]
+            rec["sum_rgb_per_frame"] = [float(img[i, :, :, :3].astype(np.float64).sum()) for i in range(2)]
+            rec["llvmpipe_ms"] = info["ms"]
+            rec["threads"] = T
+        (GOLD / "c5_sponza_synth_3840x2160_b4.json").write_text(json.dumps(rec, indent=1))
     if want("big"):
         # byte-level pins for the native scene pipeline on large inputs: only hashes are kept
         from raytracer_amd import synth

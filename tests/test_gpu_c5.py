@@ -1,6 +1,7 @@
 """The 4K tile-and-sample-sharded configuration (3840x2160, sponza-scale scene, 4 bounces) on one
 GPU: the shards of a multi-GPU run, rendered one after another into one sum image, must add up to
-the unsharded image; a crop is checked against the CPU oracle.  Also the RCCL entry points with a
+the unsharded image; whole frames are checked against the reference shader's own 4K output and a
+crop against the CPU oracle.  Also the RCCL entry points with a
 one-rank communicator (all a one-GPU machine can form)."""
 
 import ctypes as C
@@ -111,6 +112,27 @@ def test_4k_frame_crop_is_bit_identical_to_the_oracle(setup):
     # a corner too (edge tiles)
     ref = sc.render_window(W, H, W - 64, H - 32, 64, 32, 255, BOUNCES)
     assert np.array_equal(img[H - 32:, W - 64:].view(np.uint32), ref.view(np.uint32))
+
+
+def test_4k_frames_are_the_reference_shaders(setup):
+    """Two whole 3840x2160 frames against the reference's compute.glsl on llvmpipe
+    (oracle/gen_fixtures.py --only sponza4k; hashes only), in both traversal variants' kernels:
+    the frames go through whichever the library picked, and the sum of a one-frame sum image
+    (the kernel the multi-GPU ranks run) decodes from the same radiance."""
+    import json
+
+    from util import GOLDEN, sha
+
+    rec = json.loads((GOLDEN / "c5_sponza_synth_3840x2160_b4.json").read_text())
+    assert (rec["w"], rec["h"], rec["bounces"]) == (W, H, BOUNCES)
+    r, _ = setup
+    f0, f1 = rec["frames"]
+    for i, f in enumerate(range(f0, f1)):
+        r.set_frame_index(f)
+        r.set_flags()
+        r.camera.changed = False
+        r.render()
+        assert sha(r.read_sample()) == rec["sample_sha256_per_frame"][i], f"frame {f}"
 
 
 def test_rccl_entry_points_with_a_one_rank_communicator(setup):

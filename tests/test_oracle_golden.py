@@ -192,6 +192,10 @@ def test_bench_workload_first_frame():
     assert sha(aux[..., 2]) == rec["primary_sha256"]["exists"]
     # the counter-instrumented shader variant compiles slightly differently in rare pixels
     assert abs(cnt["rays"] - rec["rays_frame0"]) <= 1e-5 * rec["rays_frame0"]
+    # the same scene at configuration C5's size, 3840x2160: one whole frame against the reference shader
+    rec4k = json.loads((GOLDEN / "c5_sponza_synth_3840x2160_b4.json").read_text())
+    assert rec4k["buffers_sha256"] == rec["buffers_sha256"]
+    assert sha(sc.render(rec4k["w"], rec4k["h"], 1, rec4k["bounces"])) == rec4k["sample_sha256_per_frame"][1]
 
 
 def test_random_scenes_bit_exact():
