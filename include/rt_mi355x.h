@@ -113,6 +113,15 @@ int rt_rendered_frames(rt_ctx *ctx, uint32_t *out);
 int rt_read_sample(rt_ctx *ctx, float *rgba);
 /* The accumulation image (`_last_frame` / `_color_tex`, renderer.py:274-286), sRGB-encoded. */
 int rt_read_accumulation(rt_ctx *ctx, float *rgba);
+/* The same two images without a copy into caller memory: the library reads the image back into a
+ * page-locked host buffer of its own (allocated at the first call, width*height RGBA32F) and
+ * hands out its address.  The transfer runs at the PCIe rate (a copy into pageable caller memory
+ * runs at a fraction of it), which is what an interactive loop that presents every frame wants
+ * (renderer.py:294-300 samples the texture directly; a host presents it with glTexSubImage2D).
+ * `which`: RT_IMAGE_SAMPLE or RT_IMAGE_ACCUMULATION.  *rgba stays valid, and its contents
+ * unchanged, until the next rt_map_image, rt_resize or rt_destroy on this context. */
+enum { RT_IMAGE_SAMPLE = 0, RT_IMAGE_ACCUMULATION = 1 };
+int rt_map_image(rt_ctx *ctx, int which, const float **rgba);
 /* Parity record of the last frame rendered with RT_FLAG_AUX: 16 u32 per pixel,
  *   [0] type<<30|index of the primitive the first ray hit (0xFFFFFFFF: none), [1] bits of that
  *   ray's hit distance, [2] hit exists, [3] node visits (RT_FLAG_STATS), [4..6] ray direction,

@@ -22,6 +22,7 @@ SYMBOLS = (
     "rt_finalize_sum", "rt_render_noalloc", "rt_comm_unique_id", "rt_comm_init", "rt_comm_reduce_sum",
     "rt_comm_all_reduce_f64", "rt_comm_barrier", "rt_set_fast_mode", "rt_fast_bvh_size", "rt_fast_bvh_export",
     "rt_traversal_variant",
+    "rt_map_image",
 )
 RT_COMM_ID_BYTES = 128
 RT_COMM_SUM, RT_COMM_MAX = 0, 1
@@ -88,6 +89,7 @@ def load():
         "rt_fast_bvh_size": [vp, C.POINTER(C.c_uint32)],
         "rt_fast_bvh_export": [vp, vp, C.c_size_t],
         "rt_traversal_variant": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "rt_map_image": [vp, C.c_int, C.POINTER(C.POINTER(C.c_float))],
         "rt_comm_unique_id": [C.c_char_p],
         "rt_comm_init": [vp, C.c_int, C.c_int, C.c_char_p],
         "rt_comm_reduce_sum": [vp, vp, C.c_int],

@@ -139,6 +139,8 @@ struct rt_ctx {
     // keeps the variant instead of paying four launches per upload
     uint64_t tuned_records = 0, tuned_pixels = 0;
     uint32_t plain_frames = 0;  // plain frames rendered since the scene or the size changed, while undecided
+    float *pinned = nullptr;  // page-locked host image handed out by rt_map_image
+    size_t pinned_bytes = 0;
     uint32_t extend_waves = 8192;
     uint32_t refill_threshold = 16;
 };
@@ -211,6 +213,10 @@ int alloc_images(rt_ctx *c, int width, int height) {
     if (c->aux) {
         (void)hipFree(c->aux);
         c->aux = nullptr;
+    }
+    if (c->pinned) {  // pointers handed out by rt_map_image end here
+        (void)hipHostFree(c->pinned);
+        c->pinned = nullptr, c->pinned_bytes = 0;
     }
     c->W = width;
     c->H = height;
@@ -587,6 +593,7 @@ int rt_destroy(rt_ctx *c) {
         if (b->packed) (void)hipFree(b->packed);
     }
     if (c->fnodes) (void)hipFree(c->fnodes);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     for (void *p : {(void *)c->node_order, (void *)c->node_rank, (void *)c->sample, (void *)c->sample2, (void *)c->acc,
                     (void *)c->sum, (void *)c->sum2, (void *)c->aux, (void *)c->counters, (void *)c->q.rays[0],
                     (void *)c->q.hits, (void *)c->q.paths})
@@ -759,6 +766,23 @@ int rt_read_accumulation(rt_ctx *c, float *rgba) {
 }
 int rt_read_aux(rt_ctx *c, uint32_t *aux16) {
     return read_image(c, c ? c->aux : nullptr, aux16, c ? (size_t)c->W * c->H * 64 : 0, "rt_read_aux");
+}
+
+int rt_map_image(rt_ctx *c, int which, const float **rgba) {
+    if (!c || !rgba) return fail("rt_map_image: null argument");
+    if (which != RT_IMAGE_SAMPLE && which != RT_IMAGE_ACCUMULATION) return fail("rt_map_image: unknown image");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->W * c->H * sizeof(float4);
+    if (!c->pinned) {
+        HIP_TRY(hipHostMalloc((void **)&c->pinned, bytes, hipHostMallocDefault));
+        c->pinned_bytes = bytes;
+    }
+    const float4 *dev = which == RT_IMAGE_ACCUMULATION ? c->acc : (c->last_sample ? c->sample2 : c->sample);
+    if (int rc = join(c)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->pinned, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *rgba = c->pinned;
+    return 0;
 }
 
 int rt_sync(rt_ctx *c) {

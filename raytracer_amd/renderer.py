@@ -193,6 +193,16 @@ class Renderer:
         """(H, W, 4) float32, row 0 = bottom: the running mean, sRGB-encoded."""
         return self._read(self._L.rt_read_accumulation, np.float32, 4)
 
+    def map_image(self, accumulation: bool = True) -> np.ndarray:
+        """(H, W, 4) float32 read-only view of the accumulation image (or the last sample) in the
+        library's own page-locked buffer: no copy into Python memory, transfer at the PCIe rate.
+        Valid, and unchanged, until the next map_image(), update_size() or close()."""
+        p = C.POINTER(C.c_float)()
+        _lib.check(self._L.rt_map_image(self._ctx, 1 if accumulation else 0, C.byref(p)))
+        a = np.ctypeslib.as_array(p, shape=(self._height, self._width, 4))
+        a.flags.writeable = False
+        return a
+
     def read_aux(self) -> np.ndarray:
         return self._read(self._L.rt_read_aux, np.uint32, 16)
 

@@ -529,6 +529,31 @@ def test_finalize_then_more_frames_without_clear(renderer):
             assert np.array_equal(img.view(np.uint32), preview_of(tot).view(np.uint32)), f"preview after frame {f}"
 
 
+def test_mapped_images_equal_the_copied_ones(renderer):
+    """rt_map_image: the page-locked view holds what rt_read_* copies out, stays unchanged while
+    further frames render, and follows a resize."""
+    load_golden_scene(renderer, "debug")
+    render_frame(renderer, 320, 180, 0, 3)
+    render_frame(renderer, 320, 180, 1, 3)
+    acc = renderer.map_image()
+    assert acc.shape == (180, 320, 4) and not acc.flags.writeable
+    assert np.array_equal(acc.view(np.uint32), renderer.read_accumulation().view(np.uint32))
+    kept = acc.copy()
+    render_frame(renderer, 320, 180, 2, 3)  # rendering on does not touch the mapped image
+    assert np.array_equal(acc, kept)
+    smp = renderer.map_image(accumulation=False)  # the same buffer, now holding the last sample
+    assert np.array_equal(smp.view(np.uint32), renderer.read_sample().view(np.uint32))
+    render_frame(renderer, 160, 88, 0, 3)
+    small = renderer.map_image()
+    assert small.shape == (88, 160, 4)
+    assert np.array_equal(small.view(np.uint32), renderer.read_accumulation().view(np.uint32))
+    with pytest.raises(RuntimeError):
+        from raytracer_amd import _lib
+        import ctypes as C
+        p = C.POINTER(C.c_float)()
+        _lib.check(_lib.load().rt_map_image(renderer._ctx, 2, C.byref(p)))
+
+
 def test_failed_resize_keeps_the_context_usable(renderer):
     """rt_resize refuses an absurd size with a message and leaves the previous images in place."""
     load_golden_scene(renderer, "debug")
