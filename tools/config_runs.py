@@ -45,7 +45,7 @@ def run_mean(name, bufs, w, h, spp, bounces, golden_acc_hash=None):
     r.sync()
     t_rest = time.perf_counter() - t1
     t2 = time.perf_counter()
-    img = r.read_accumulation()
+    img = r.map_image()  # page-locked view, no copy into Python memory
     t_read = time.perf_counter() - t2
     rays = r.stats()["rays"]
     # steady state: the same frames once more, outside the run's own clock and after a batch long
@@ -82,7 +82,7 @@ def run_sum(name, bufs, w, h, spp, bounces):
     r.sync()
     t_dev = time.perf_counter() - t0
     t2 = time.perf_counter()
-    r.read_accumulation()
+    r.map_image()
     t_read = time.perf_counter() - t2
     rays = r.stats()["rays"]
     variant = r.traversal_variant()[0]
