@@ -139,6 +139,17 @@ struct rt_ctx {
     // keeps the variant instead of paying four launches per upload
     uint64_t tuned_records = 0, tuned_pixels = 0;
     uint32_t plain_frames = 0;  // plain frames rendered since the scene or the size changed, while undecided
+    // Macro tiles in the order of what they cost in the previous frame of the same parity, most
+    // expensive first, so that a launch does not end on a few long-running workgroups (RT_LPT=0
+    // turns it off).  Any order renders every pixel exactly once; only the launch's tail changes.
+    // Used for frames that run alone (RT_OVERLAP=0, or no earlier frame still on the device when
+    // the frame is queued, as in an interactive loop that reads every frame back): 2.6 % off a
+    // launch there; when frames overlap, the next frame fills the tail anyway and the ordering pass
+    // only costs (0.6 %).
+    hipEvent_t ev_busy[2] = {nullptr, nullptr};  // end of the last trace kernel queued on trace stream b
+    bool busy_recorded[2] = {false, false};
+    bool lpt = true;
+    uint32_t *lpt_cost[2] = {nullptr, nullptr}, *lpt_order[2] = {nullptr, nullptr};
     float *pinned = nullptr;  // page-locked host image handed out by rt_map_image
     size_t pinned_bytes = 0;
     uint32_t extend_waves = 8192;
@@ -397,6 +408,31 @@ void fill_params(rt_ctx *c, rt::TraceParams *p) {
     p->tiles_x = (uint32_t)((p->WW + 15) / 16);
     p->tiles_y = (uint32_t)((p->HH + 15) / 16);
     p->ntiles = p->tiles_x * p->tiles_y;
+    p->order = nullptr;
+    p->cost = nullptr;
+}
+
+// number of 2x2-tile macro tiles of the frame (the unit the megakernel deals to the XCDs)
+uint32_t macro_tiles(const rt::TraceParams &p) { return ((p.tiles_x + 1u) / 2u) * ((p.tiles_y + 1u) / 2u); }
+
+// Queues the ordering pass for a frame of parity b on stream s and points the frame at its result.
+int order_tiles(rt_ctx *c, rt::TraceParams *p, int b, bool serial, hipStream_t s) {
+    p->order = nullptr, p->cost = nullptr;
+    const uint32_t n = macro_tiles(*p);
+    if (!c->lpt || c->pipeline != 0 || n > 8u * rt::kLptPerXcd) return 0;
+    if (!serial)  // is a frame queued earlier still on the device?  then this one will not run alone
+        for (int k = 0; k < 2; k++)
+            if (c->busy_recorded[k]) {
+                if (hipEventQuery(c->ev_busy[k]) == hipErrorNotReady) {
+                    (void)hipGetLastError();  // "not ready" is an answer, not a failure to report later
+                    return 0;
+                }
+                c->busy_recorded[k] = false;
+            }
+    rt::launch_lpt_sort(c->lpt_cost[b], c->lpt_order[b], n, s);
+    p->order = c->lpt_order[b];
+    p->cost = c->lpt_cost[b];
+    return 0;
 }
 
 // pixels of the covered area that belong to `shard`: 64x64 macro tiles dealt round-robin in
@@ -532,11 +568,18 @@ static int create_impl(rt_ctx *c, int device) {
         HIP_TRY(hipEventCreateWithFlags(&c->ev_tdone[b], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_acc[b], hipEventDisableTiming));
         HIP_TRY(hipEventCreate(&c->ev_tlast[b]));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_busy[b], hipEventDisableTiming));
     }
     for (hipEvent_t &e : c->ev_tune) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipMalloc((void **)&c->tune_counters, sizeof(rt::Counters) * rt::kCounterStripes));
     HIP_TRY(hipMemsetAsync(c->tune_counters, 0, sizeof(rt::Counters) * rt::kCounterStripes, c->stream));
     if (const char *e = getenv("RT_OVERLAP")) c->overlap = atoi(e) != 0;
+    if (const char *e = getenv("RT_LPT")) c->lpt = atoi(e) != 0;
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(hipMalloc((void **)&c->lpt_cost[b], 8u * rt::kLptPerXcd * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&c->lpt_order[b], 8u * rt::kLptPerXcd * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(c->lpt_cost[b], 0, 8u * rt::kLptPerXcd * sizeof(uint32_t), c->stream));
+    }
     if (const char *e = getenv("RT_LEAF_STEPS")) {
         c->leaf_steps = atoi(e) != 0;
         c->tune_fixed = true;
@@ -594,6 +637,8 @@ int rt_destroy(rt_ctx *c) {
     }
     if (c->fnodes) (void)hipFree(c->fnodes);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    for (void *p : {(void *)c->lpt_cost[0], (void *)c->lpt_cost[1], (void *)c->lpt_order[0], (void *)c->lpt_order[1]})
+        if (p) (void)hipFree(p);
     for (void *p : {(void *)c->node_order, (void *)c->node_rank, (void *)c->sample, (void *)c->sample2, (void *)c->acc,
                     (void *)c->sum, (void *)c->sum2, (void *)c->aux, (void *)c->counters, (void *)c->q.rays[0],
                     (void *)c->q.hits, (void *)c->q.paths})
@@ -603,7 +648,7 @@ int rt_destroy(rt_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     if (c->tune_counters) (void)hipFree(c->tune_counters);
     for (hipEvent_t e : {c->ev_begin, c->ev_end, c->ev_ready, c->ev_tdone[0], c->ev_tdone[1], c->ev_acc[0], c->ev_acc[1],
-                         c->ev_tlast[0], c->ev_tlast[1]})
+                         c->ev_tlast[0], c->ev_tlast[1], c->ev_busy[0], c->ev_busy[1]})
         if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : {c->tstream[0], c->tstream[1], c->stream})
         if (st) (void)hipStreamDestroy(st);
@@ -712,8 +757,13 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounces, 
         if (int rc = trace_stream(c, b, serial, &ts)) return rc;
         // the accumulate pass that last read this sample image must be done before it is rewritten
         if (ts != c->stream && c->acc_recorded[b]) HIP_TRY(hipStreamWaitEvent(ts, c->ev_acc[b], 0));
+        if (int rc = order_tiles(c, &p, b, serial, ts)) return rc;
         if (int rc = trace_event(c, ts)) return rc;
         trace_frame(c, p, 0, aux, stats, ts);
+        if (ts != c->stream) {
+            HIP_TRY(hipEventRecord(c->ev_busy[b], ts));
+            c->busy_recorded[b] = true;
+        }
         c->pixel_samples += (uint64_t)p.WW * (uint64_t)p.HH;
         if (int rc = trace_event(c, ts)) return rc;
         if (ts != c->stream) {
@@ -874,8 +924,13 @@ int rt_render_sum(rt_ctx *c, uint32_t first_frame, uint32_t nframes, float bounc
         hipStream_t ts;
         if (int rc = trace_stream(c, b, serial, &ts)) return rc;
         p.sum = (b && !serial) ? c->sum2 : target;
+        if (int rc = order_tiles(c, &p, b, serial, ts)) return rc;
         if (int rc = trace_event(c, ts)) return rc;
         trace_frame(c, p, 1, false, false, ts);
+        if (ts != c->stream) {
+            HIP_TRY(hipEventRecord(c->ev_busy[b], ts));
+            c->busy_recorded[b] = true;
+        }
         c->pixel_samples += owned;
         if (int rc = trace_event(c, ts)) return rc;
         if (ts != c->stream) {

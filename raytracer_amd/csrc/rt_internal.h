@@ -69,7 +69,14 @@ struct TraceParams {
     Counters *counters;
     uint32_t shard, nshards;  // mode 1 tile ownership
     uint32_t tiles_x, tiles_y, ntiles;  // 16x16 pixel tiles
+    // Order of the macro tiles within each XCD (kLptPerXcd entries per XCD) and where the wavefronts
+    // add the cycles they took, per macro tile; both null: macro tiles in index order, nothing recorded.
+    const uint32_t *order;
+    uint32_t *cost;
 };
+constexpr uint32_t kLptPerXcd = 1024;  // macro tiles per XCD the ordering can hold
+// sorts every XCD's macro tiles by the cost recorded for them (most expensive first) and clears the costs
+void launch_lpt_sort(uint32_t *cost, uint32_t *order, uint32_t n_macro, hipStream_t s);
 
 // ---- wavefront pipeline: ray queue in device memory ----------------------------------------
 struct WaveQueues {

@@ -1085,15 +1085,18 @@ __device__ __forceinline__ bool tile_pixel(const TraceParams &p, bool sharded, i
 // the XCD and b >> 3 counts within it.  Macro tiles (RT_MACRO x RT_MACRO tiles) are dealt to the
 // XCDs in turn: an XCD works on compact screen regions (its rays share nodes in its L2) while
 // every XCD gets an equal share of cheap and expensive parts of the image.
-__device__ __forceinline__ bool trace_pixel(const TraceParams &p, bool sharded, int &x, int &y) {
+__device__ __forceinline__ bool trace_pixel(const TraceParams &p, bool sharded, int &x, int &y, uint32_t &macro_out) {
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u;
     uint32_t tx, ty, wave;
     static_assert((RT_MACRO * RT_MACRO * 4) % RT_TRACE_WAVES == 0, "a workgroup must not straddle macro tiles");
     const uint32_t mxn = (p.tiles_x + RT_MACRO - 1) / RT_MACRO, myn = (p.tiles_y + RT_MACRO - 1) / RT_MACRO;
     // j: index of this wavefront among those of its XCD
     const uint32_t j = (b >> 3) * RT_TRACE_WAVES + (threadIdx.x >> 6), per_macro = RT_MACRO * RT_MACRO * 4u;
-    const uint32_t macro = (j / per_macro) * 8u + (b & 7u), r = j % per_macro;
-    if (macro >= mxn * myn) return false;
+    const uint32_t k = j / per_macro, r = j % per_macro, xcd = b & 7u;
+    macro_out = 0xFFFFFFFFu;
+    if (k * 8u + xcd >= mxn * myn) return false;  // k is beyond this XCD's share
+    const uint32_t macro = p.order ? p.order[xcd * kLptPerXcd + k] : k * 8u + xcd;
+    macro_out = macro;
     const uint32_t t = r >> 2;
     wave = r & 3u;
     tx = (macro % mxn) * RT_MACRO + (t % RT_MACRO);
@@ -1160,7 +1163,9 @@ __device__ __forceinline__ void trace_body(const TraceParams &p) {
     __syncthreads();
     LdsTop top = (LdsTop)lds_top;
     int x, y;
-    bool live = trace_pixel(p, true, x, y);
+    uint32_t macro;
+    const unsigned long long t_begin = p.cost ? __builtin_readcyclecounter() : 0ull;
+    bool live = trace_pixel(p, true, x, y, macro);
     uint32_t lane = threadIdx.x & 63u;
     uint32_t *stack = lds_stack + threadIdx.x;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};
@@ -1203,6 +1208,36 @@ __device__ __forceinline__ void trace_body(const TraceParams &p) {
         }
     }
     flush_counters<STATS>(p.counters, lane, nrays, st);
+    if (p.cost && lane == 0u && macro != 0xFFFFFFFFu)
+        atomicAdd(&p.cost[macro], (uint32_t)((__builtin_readcyclecounter() - t_begin) >> 6));
+}
+
+// One workgroup per XCD: its macro tiles (indices x, x + 8, x + 16, ...) sorted by recorded cost,
+// most expensive first, ties by index; the costs are cleared for the next frame.
+__global__ __launch_bounds__(1024) void lpt_sort_kernel(uint32_t *cost, uint32_t *order, uint32_t n_macro) {
+    __shared__ unsigned long long key[kLptPerXcd];
+    const uint32_t xcd = blockIdx.x, t = threadIdx.x;
+    const uint32_t n = (n_macro + 7u - xcd) / 8u;  // this XCD's macro tiles
+    const uint32_t m = t * 8u + xcd;
+    // sorted ascending: a larger cost gives a smaller key, then the smaller index; padding goes last
+    key[t] = t < n ? ((unsigned long long)(0xFFFFFFFFu - cost[m]) << 32) | m : ~0ull;
+    if (t < n) cost[m] = 0u;
+    __syncthreads();
+    for (uint32_t size = 2u; size <= kLptPerXcd; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0u; stride >>= 1) {
+            const uint32_t partner = t ^ stride;
+            if (partner > t) {
+                const bool up = (t & size) == 0u;
+                const unsigned long long a = key[t], b = key[partner];
+                if ((a > b) == up) key[t] = b, key[partner] = a;
+            }
+            __syncthreads();
+        }
+    if (t < n) order[xcd * kLptPerXcd + t] = (uint32_t)key[t];
+}
+
+void launch_lpt_sort(uint32_t *cost, uint32_t *order, uint32_t n_macro, hipStream_t s) {
+    hipLaunchKernelGGL(lpt_sort_kernel, dim3(8), dim3(kLptPerXcd), 0, s, cost, order, n_macro);
 }
 
 template <int MODE, bool AUX, bool STATS, bool FAST = false>
@@ -1253,7 +1288,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_regroup_kernel(T
     __syncthreads();
     LdsTop top = (LdsTop)lds_top;
     int x, y;
-    const bool live = trace_pixel(p, true, x, y);
+    uint32_t macro_unused;
+    const bool live = trace_pixel(p, true, x, y, macro_unused);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0, path_visits = 0;

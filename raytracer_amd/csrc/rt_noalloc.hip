@@ -172,6 +172,8 @@ extern "C" int rt_render_noalloc(int device, const rt_scene_view *sv, int width,
     p.sample = reinterpret_cast<float4 *>(sample_rgba);
     p.sum = nullptr;
     p.aux = nullptr;
+    p.order = nullptr;  // macro tiles in index order: an ordering by cost would need buffers of its own
+    p.cost = nullptr;
     p.counters = counters;
     p.shard = 0;
     p.nshards = 1;
