@@ -412,8 +412,10 @@ void fill_params(rt_ctx *c, rt::TraceParams *p) {
     p->cost = nullptr;
 }
 
-// number of 2x2-tile macro tiles of the frame (the unit the megakernel deals to the XCDs)
-uint32_t macro_tiles(const rt::TraceParams &p) { return ((p.tiles_x + 1u) / 2u) * ((p.tiles_y + 1u) / 2u); }
+// number of macro tiles of the frame (the unit the megakernel deals to the XCDs)
+uint32_t macro_tiles(const rt::TraceParams &p) {
+    return ((p.tiles_x + RT_MACRO - 1u) / RT_MACRO) * ((p.tiles_y + RT_MACRO - 1u) / RT_MACRO);
+}
 
 // Queues the ordering pass for a frame of parity b on stream s and points the frame at its result.
 int order_tiles(rt_ctx *c, rt::TraceParams *p, int b, bool serial, hipStream_t s) {

@@ -74,6 +74,9 @@ struct TraceParams {
     const uint32_t *order;
     uint32_t *cost;
 };
+#ifndef RT_MACRO
+#define RT_MACRO 2  // a macro tile is RT_MACRO x RT_MACRO tiles of 16x16 pixels; the host counts them too
+#endif
 constexpr uint32_t kLptPerXcd = 1024;  // macro tiles per XCD the ordering can hold
 // sorts every XCD's macro tiles by the cost recorded for them (most expensive first) and clears the costs
 void launch_lpt_sort(uint32_t *cost, uint32_t *order, uint32_t n_macro, hipStream_t s);

@@ -41,9 +41,7 @@ namespace rt {
 #ifndef RT_FAST_TOP
 #define RT_FAST_TOP 192    // fast mode: leading nodes (64 bytes each) kept in LDS per workgroup: 12 KB
 #endif
-#ifndef RT_MACRO
-#define RT_MACRO 2    // megakernel tile placement: macro tile = RT_MACRO x RT_MACRO tiles of 16x16 pixels, dealt to the XCDs in turn
-#endif
+// RT_MACRO (rt_internal.h): megakernel tile placement, macro tile = RT_MACRO x RT_MACRO tiles of 16x16 pixels, dealt to the XCDs in turn
 #ifndef RT_EXT_STACK_LDS
 #define RT_EXT_STACK_LDS 8   // traversal kernel of the wavefront pipeline: 2 KB of LDS stack per wavefront
 #endif

@@ -554,6 +554,44 @@ def test_mapped_images_equal_the_copied_ones(renderer):
         _lib.check(_lib.load().rt_map_image(renderer._ctx, 2, C.byref(p)))
 
 
+def test_tile_ordering_renders_every_pixel_exactly_once(renderer):
+    """Frames that run alone have their macro tiles launched in the order of their cost in the
+    previous frame (RT_LPT, on by default).  At sizes with partial tiles and partial macro tiles,
+    over several frames: every covered pixel gets exactly one sample per frame, and the sum image is
+    bit for bit the one a context without the ordering produces."""
+    import os
+
+    from raytracer_amd.renderer import Renderer
+
+    os.environ["RT_LPT"] = "0"
+    os.environ["RT_PIPELINE"] = renderer.pipeline_name
+    try:
+        plain = Renderer(device=0, singleton=False)
+    finally:
+        os.environ.pop("RT_LPT", None)
+        os.environ.pop("RT_PIPELINE", None)
+    try:
+        sums = []
+        for r in (renderer, plain):
+            load_golden_scene(r, "gally")
+            r.bounces = 3
+            per_size = []
+            for (w, h) in ((129, 66), (1000, 600), (37, 23)):
+                r.update_size(w, h)
+                r.clear_sum()
+                for f in range(5):
+                    r.render_sum(f, 1)
+                    r.sync()  # the next frame finds the device idle: it runs alone
+                per_size.append(r.read_sum())
+            sums.append(per_size)
+        for (w, h), a, b in zip(((129, 66), (1000, 600), (37, 23)), *sums):
+            ww, hh = (w // 8) * 8, (h // 4) * 4
+            assert np.all(a[:hh, :ww, 3] == 5) and np.all(a[hh:, :, 3] == 0) and np.all(a[:, ww:, 3] == 0), (w, h)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (w, h)
+    finally:
+        plain.close()
+
+
 def test_failed_resize_keeps_the_context_usable(renderer):
     """rt_resize refuses an absurd size with a message and leaves the previous images in place."""
     load_golden_scene(renderer, "debug")
