@@ -1082,7 +1082,10 @@ __device__ __forceinline__ bool tile_pixel(const TraceParams &p, bool sharded, i
 // Consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2, so b & 7 names
 // the XCD and b >> 3 counts within it.  Macro tiles (RT_MACRO x RT_MACRO tiles) are dealt to the
 // XCDs in turn: an XCD works on compact screen regions (its rays share nodes in its L2) while
-// every XCD gets an equal share of cheap and expensive parts of the image.
+// every XCD gets an equal share of cheap and expensive parts of the image.  XCD x owns the macro
+// tiles x, x + 8, x + 16, ...; the order in which it works through them is their index order, or,
+// if p.order is set, the order listed there (lpt_sort_kernel: most expensive first).  macro_out
+// receives the macro tile of this wavefront (0xFFFFFFFF: none).
 __device__ __forceinline__ bool trace_pixel(const TraceParams &p, bool sharded, int &x, int &y, uint32_t &macro_out) {
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u;
     uint32_t tx, ty, wave;
