@@ -431,6 +431,8 @@ int order_tiles(rt_ctx *c, rt::TraceParams *p, int b, bool serial, hipStream_t s
                 }
                 c->busy_recorded[k] = false;
             }
+    // a frame on the main stream uses these buffers too: later frames on the trace streams must see it finished
+    if (s == c->stream) c->main_dirty = true;
     rt::launch_lpt_sort(c->lpt_cost[b], c->lpt_order[b], n, s);
     p->order = c->lpt_order[b];
     p->cost = c->lpt_cost[b];

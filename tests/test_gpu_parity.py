@@ -592,6 +592,31 @@ def test_tile_ordering_renders_every_pixel_exactly_once(renderer):
         plain.close()
 
 
+def test_recorded_frame_followed_at_once_by_sum_frames(renderer):
+    """A frame with the per-pixel record runs on the main stream, sum-mode frames on the trace
+    streams, and both take their tile order from the same buffers: queued back to back without a
+    wait in between, the recorded frame must still render every pixel once (its image is the
+    oracle's) and so must the sum frames."""
+    load_golden_scene(renderer, "gally")
+    w, h, b = 640, 360, 4
+    renderer.update_size(w, h)
+    renderer.bounces = b
+    sc = O.OracleScene.from_dir(GOLDEN / "gally")
+    ref = {f: sc.render(w, h, f, b) for f in (0, 1)}
+    for rep in range(6):
+        f = rep & 1
+        renderer.clear_sum()
+        renderer.set_frame_index(f)
+        renderer.set_flags(aux=True)
+        renderer.camera.changed = False
+        renderer.render()               # main stream, no wait
+        renderer.render_sum(10 + rep, 3)  # trace streams, no wait
+        img = renderer.read_sample()
+        assert np.array_equal(img.view(np.uint32), ref[f].view(np.uint32)), rep
+        assert np.all(renderer.read_sum()[..., 3] == 3), rep
+    renderer.set_flags()
+
+
 def test_failed_resize_keeps_the_context_usable(renderer):
     """rt_resize refuses an absurd size with a message and leaves the previous images in place."""
     load_golden_scene(renderer, "debug")
