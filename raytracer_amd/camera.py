@@ -13,9 +13,11 @@ definitions:
 * object product ``A * B`` == ``numpy.dot(B, A)``
 * ``~M`` == ``numpy.linalg.inv(M)``
 
-Parity of this restatement with pyrr is pinned only by the known-answer
-uniform words recorded from a reference run (tests/test_camera.py); kernel
-parity never depends on it because both sides consume the same 16 floats.
+Parity of this restatement with pyrr itself is unpinned: the known-answer
+uniform words in tests/test_scene_pipeline.py (test_camera_known_answer) come
+from an independent numpy evaluation of the same published formulas, not from
+pyrr.  Kernel parity never depends on it, because both sides consume the same
+16 floats.
 """
 
 from __future__ import annotations
