@@ -86,38 +86,72 @@ def camera_uniforms(cam: dict):
     return c.uniforms_f32()
 
 
+def dense_scene(rng: np.random.Generator, case: int, n_spheres: int, n_boxes: int, n_quads: int) -> tuple[dict, dict]:
+    """Hundreds of small spheres and boxes (deep trees whose leaves are mostly not triangles: every
+    position of a sphere record within its 128-byte line, box leaves at every depth)."""
+    scene, cam = random_scene(rng, case)
+    nm = len(scene["materials"])
+    scene["spheres"] = [s for s in scene["spheres"] if s["radius"] >= 40.0]  # keep the emissive shell if drawn
+    scene["boxes"], scene["quads"] = [], scene["quads"][:n_quads]
+    for _ in range(n_spheres):
+        scene["spheres"].append({"center": r3(rng, -6, 6), "radius": round(float(rng.uniform(0.05, 0.6)), 3),
+                                 "material": int(rng.integers(0, nm))})
+    for _ in range(n_boxes):
+        p0 = np.array(r3(rng, -6, 6))
+        scene["boxes"].append({"p0": [float(x) for x in p0], "p1": [float(x) for x in p0 + rng.uniform(0.05, 0.9, 3).round(3)],
+                               "material": int(rng.integers(0, nm))})
+    return scene, cam
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=24)
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--dense", action="store_true",
+                    help="add the dense sphere / box cases after the existing ones instead of redrawing those")
     args = ap.parse_args()
     OUT.mkdir(parents=True, exist_ok=True)
+    if args.dense:
+        first = len(sorted(OUT.glob("case*.json")))
+        firsts = dict(np.load(OUT / "first_frames.npz"))
+        rng = np.random.default_rng(args.seed + 1)
+        for k, (ns, nb, nq) in enumerate(((300, 0, 2), (0, 250, 2), (200, 150, 3), (500, 300, 0))):
+            case = first + k
+            scene, cam = dense_scene(rng, case, ns, nb, nq)
+            write_case(case, scene, cam, int(rng.integers(3, 7)), firsts, args.threads)
+        np.savez_compressed(OUT / "first_frames.npz", **firsts)
+        return
     rng = np.random.default_rng(args.seed)
     firsts = {}
     for case in range(args.cases):
         scene, cam = random_scene(rng, case)
-        b = refscene.build_reference_scene(scene, [])
-        inv_vp, eye = camera_uniforms(cam)
-        uni = np.concatenate([inv_vp, eye, b["scene_min"], b["scene_extent"]]).astype(np.float32)
-        bounces = int(rng.integers(2, 9))
-        with tempfile.TemporaryDirectory(prefix="rtfuzz_") as td:
-            td = Path(td)
-            for key in ("mats", "spheres", "tris", "bvh", "boxes", "planes"):
-                (td / f"{key}.bin").write_bytes(b[key])
-            uni.tofile(td / "uniforms.bin")
-            img, _ = G.run_shader("color", td, W, H, bounces, 0, 3, args.threads)
-            prim, _ = G.run_shader("primary", td, W, H, bounces, 0, 1, args.threads)
-        rec = {"scene": scene, "camera": cam, "uniform_words": ["%08x" % x for x in uni.view(np.uint32)],
-               "w": W, "h": H, "bounces": bounces, "frames": [0, 3],
-               "buffers_sha256": {k: G.sha(b[k]) for k in ("mats", "spheres", "tris", "bvh", "boxes", "planes")},
-               "sample_sha256_per_frame": [G.sha(img[i]) for i in range(3)],
-               "lit_fraction": float((img[0, :, :, :3].sum(-1) > 0).mean())}
-        (OUT / f"case{case:02d}.json").write_text(json.dumps(rec, indent=1))
-        firsts[f"color{case:02d}"] = img[0]
-        firsts[f"primary{case:02d}"] = prim[0]
-        print(case, bounces, "lit", round(rec["lit_fraction"], 3), flush=True)
+        write_case(case, scene, cam, int(rng.integers(2, 9)), firsts, args.threads)
     np.savez_compressed(OUT / "first_frames.npz", **firsts)
+
+
+def write_case(case, scene, cam, bounces, firsts, threads):
+    """Buffers from the reference's classes, three frames and the first-hit record from the reference
+    shader on llvmpipe; the record goes to caseNN.json, the first frame's images into `firsts`."""
+    b = refscene.build_reference_scene(scene, [])
+    inv_vp, eye = camera_uniforms(cam)
+    uni = np.concatenate([inv_vp, eye, b["scene_min"], b["scene_extent"]]).astype(np.float32)
+    with tempfile.TemporaryDirectory(prefix="rtfuzz_") as td:
+        td = Path(td)
+        for key in ("mats", "spheres", "tris", "bvh", "boxes", "planes"):
+            (td / f"{key}.bin").write_bytes(b[key])
+        uni.tofile(td / "uniforms.bin")
+        img, _ = G.run_shader("color", td, W, H, bounces, 0, 3, threads)
+        prim, _ = G.run_shader("primary", td, W, H, bounces, 0, 1, threads)
+    rec = {"scene": scene, "camera": cam, "uniform_words": ["%08x" % x for x in uni.view(np.uint32)],
+           "w": W, "h": H, "bounces": bounces, "frames": [0, 3],
+           "buffers_sha256": {k: G.sha(b[k]) for k in ("mats", "spheres", "tris", "bvh", "boxes", "planes")},
+           "sample_sha256_per_frame": [G.sha(img[i]) for i in range(3)],
+           "lit_fraction": float((img[0, :, :, :3].sum(-1) > 0).mean())}
+    (OUT / f"case{case:02d}.json").write_text(json.dumps(rec, indent=1))
+    firsts[f"color{case:02d}"] = img[0]
+    firsts[f"primary{case:02d}"] = prim[0]
+    print(case, bounces, "lit", round(rec["lit_fraction"], 3), flush=True)
 
 
 if __name__ == "__main__":
