@@ -108,10 +108,30 @@ def main():
     ap.add_argument("--cases", type=int, default=24)
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--odd-materials", action="store_true",
+                    help="add cases whose materials lie far outside their meaningful ranges (ior 0, negative, 1e30, ...)")
     ap.add_argument("--dense", action="store_true",
                     help="add the dense sphere / box cases after the existing ones instead of redrawing those")
     args = ap.parse_args()
     OUT.mkdir(parents=True, exist_ok=True)
+    if args.odd_materials:
+        first = len(sorted(OUT.glob("case*.json")))
+        firsts = dict(np.load(OUT / "first_frames.npz"))
+        rng = np.random.default_rng(args.seed + 2)
+        odd_ior = [0.0, -1.5, 1e30, 1e-30, 1.0, 0.5]
+        for k in range(4):
+            case = first + k
+            scene, cam = random_scene(rng, case)
+            for i, m in enumerate(scene["materials"][1:]):
+                m["ior"] = odd_ior[(i + k) % len(odd_ior)]
+                m["transmission"] = float(rng.choice([1.0, 0.5, m.get("transmission", 0.0)]))
+                if (i + k) % 3 == 0:
+                    m["color"] = [round(float(x), 3) for x in rng.uniform(-0.5, 3.0, 3)]
+                if (i + k) % 4 == 1:
+                    m["emission"] = [round(float(x), 3) for x in rng.uniform(-1.0, 1.0, 3)] + [float(rng.choice([-5.0, 1e20, 0.0]))]
+            write_case(case, scene, cam, int(rng.integers(3, 8)), firsts, args.threads)
+        np.savez_compressed(OUT / "first_frames.npz", **firsts)
+        return
     if args.dense:
         first = len(sorted(OUT.glob("case*.json")))
         firsts = dict(np.load(OUT / "first_frames.npz"))
