@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--odd-materials", action="store_true",
                     help="add cases whose materials lie far outside their meaningful ranges (ior 0, negative, 1e30, ...)")
+    ap.add_argument("--odd-geometry", action="store_true",
+                    help="add cases with degenerate primitives (zero-area quads, radius 0 and negative, coincident copies, ...)")
     ap.add_argument("--dense", action="store_true",
                     help="add the dense sphere / box cases after the existing ones instead of redrawing those")
     args = ap.parse_args()
@@ -129,6 +131,33 @@ def main():
                     m["color"] = [round(float(x), 3) for x in rng.uniform(-0.5, 3.0, 3)]
                 if (i + k) % 4 == 1:
                     m["emission"] = [round(float(x), 3) for x in rng.uniform(-1.0, 1.0, 3)] + [float(rng.choice([-5.0, 1e20, 0.0]))]
+            write_case(case, scene, cam, int(rng.integers(3, 8)), firsts, args.threads)
+        np.savez_compressed(OUT / "first_frames.npz", **firsts)
+        return
+    if args.odd_geometry:
+        first = len(sorted(OUT.glob("case*.json")))
+        firsts = dict(np.load(OUT / "first_frames.npz"))
+        rng = np.random.default_rng(args.seed + 3)
+        for k in range(4):
+            case = first + k
+            scene, cam = random_scene(rng, case)
+            nm = len(scene["materials"])
+            # zero-area quads (their triangles get NaN normals), a sphere of radius 0 and one of negative radius
+            scene["quads"].append({"center": r3(rng, -3, 3), "width": 0.0, "height": 2.0, "normal": [0.0, 1.0, 0.0],
+                                   "material": int(rng.integers(0, nm))})
+            scene["quads"].append({"center": r3(rng, -3, 3), "width": 1.5, "height": 0.0, "normal": [1.0, 0.0, 0.0],
+                                   "material": int(rng.integers(0, nm))})
+            scene["spheres"].append({"center": r3(rng, -3, 3), "radius": 0.0, "material": int(rng.integers(0, nm))})
+            scene["spheres"].append({"center": r3(rng, -3, 3), "radius": -0.7, "material": int(rng.integers(0, nm))})
+            # coincident copies: every split of them is a tie
+            twin = {"center": r3(rng, -3, 3), "radius": 0.8, "material": int(rng.integers(0, nm))}
+            scene["spheres"] += [dict(twin) for _ in range(5)]
+            q = {"center": r3(rng, -4, 4), "width": 3.0, "height": 2.0, "normal": [0.0, 0.0, 1.0], "material": int(rng.integers(0, nm))}
+            scene["quads"] += [dict(q) for _ in range(3)]
+            # a box of no volume and a plane through the eye
+            p0 = r3(rng, -3, 3)
+            scene["boxes"].append({"p0": p0, "p1": list(p0), "material": int(rng.integers(0, nm))})
+            scene["planes"].append({"point": list(cam["position"]), "normal": [0.0, 1.0, 0.0], "material": int(rng.integers(0, nm))})
             write_case(case, scene, cam, int(rng.integers(3, 8)), firsts, args.threads)
         np.savez_compressed(OUT / "first_frames.npz", **firsts)
         return
