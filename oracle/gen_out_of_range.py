@@ -7,7 +7,8 @@ with the reference's compute.glsl on llvmpipe (oracle/_ref/llvmpipe_runner) and 
 hashes of its images and of its first-hit record in tests/golden/fuzz/damaged_gally.json; the same
 for material indices beyond the material array (damaged_materials.json) and for uniforms at the
 edges of their ranges (edge_uniforms.json: fractional and very large bounce counts, frame numbers
-beyond 2^24).  Pins the rule the oracle and the
+beyond 2^24), and for axis-parallel rays whose origin lies exactly on child-box planes
+(axis_rays.json: NaN plane distances).  Pins the rule the oracle and the
 HIP path follow for such reads: zero words, as GL robust buffer access delivers them.
 
   python oracle/gen_out_of_range.py [--threads N]
@@ -83,6 +84,44 @@ def main():
                      "sha256_per_frame": [G.sha(img[i]) for i in range(img.shape[0])]})
     (G.GOLD / "fuzz" / "edge_uniforms.json").write_text(json.dumps(runs, indent=1))
     print(json.dumps(runs, indent=1))
+
+    # rays along an axis from an origin that lies exactly on child-box planes: (plane - O) * (1 / D)
+    # is 0 * inf = NaN there, and what min / max make of a NaN decides whether the child is visited.
+    # Identity for the inverse view-projection gives every pixel the direction (0, 0, 1).
+    u0 = np.fromfile(src / "uniforms.bin", dtype=np.float32)
+    nodes = np.fromfile(src / "bvh.bin", dtype=np.uint32).reshape(-1, 16)
+    smin, sext = u0[19:22], u0[22:25]
+
+    def plane(q, a):  # compute.glsl:244-261
+        return np.float32(smin[a] + np.float32(np.float32(q) / np.float32(65535.0)) * sext[a])
+
+    cands = [(j, c) for j in range(nodes.shape[0]) for c in range(4)
+             if nodes[j][12 + c] != 0xFFFFFFFF and (nodes[j][c] >> 16) != (nodes[j][c] & 0xFFFF)
+             and (nodes[j][4 + c] >> 16) != (nodes[j][4 + c] & 0xFFFF)]
+    rng = np.random.default_rng(5)
+    rays = []
+    for trial in range(8):
+        j, c = cands[int(rng.integers(0, len(cands)))]
+        w = nodes[j]
+        ex = plane(int(w[c] & 0xFFFF), 0) if trial % 2 == 0 else plane(int(w[c] >> 16), 0)
+        ey = (plane(int(w[4 + c] & 0xFFFF), 1) if trial % 4 >= 2
+              else np.float32((plane(int(w[4 + c] & 0xFFFF), 1) + plane(int(w[4 + c] >> 16), 1)) / 2))
+        u = u0.copy()
+        u[0:16] = np.eye(4, dtype=np.float32).reshape(-1)
+        u[16:19] = [ex, ey, np.float32(smin[2] - 3.0)]
+        with tempfile.TemporaryDirectory(prefix="rtoor_") as td:
+            sdir = Path(td)
+            for name in ("bvh.bin", "tris.bin", "spheres.bin", "mats.bin"):
+                shutil.copy(src / name, sdir / name)
+            u.tofile(sdir / "uniforms.bin")
+            img, _ = G.run_shader("color", sdir, 64, 32, 3, 0, 1, args.threads)
+            prim, _ = G.run_shader("primary", sdir, 64, 32, 3, 0, 1, args.threads)
+        code, tbits, exists = O.primary_from_golden(prim[0])
+        rays.append({"node": j, "child": c, "eye_words": ["%08x" % x for x in u[16:19].view(np.uint32)], "w": 64, "h": 32,
+                     "bounces": 3, "frame": 0, "sample_sha256": G.sha(img[0]), "first_hits": int(exists.sum()),
+                     "primary_sha256": {"code": G.sha(code), "t_bits": G.sha(tbits)}})
+    (G.GOLD / "fuzz" / "axis_rays.json").write_text(json.dumps(rays, indent=1))
+    print(json.dumps(rays, indent=1)[:600])
 
 
 if __name__ == "__main__":

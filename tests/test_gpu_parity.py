@@ -144,6 +144,13 @@ def test_material_indices_outside_the_array_and_uniforms_at_the_edges(renderer):
     f0, f1 = rec["frames"]
     for i, f in enumerate(range(f0, f1)):
         assert sha(render_frame(renderer, rec["w"], rec["h"], f, rec["bounces"])) == rec["sha256_per_frame"][i], f
+    # axis-parallel rays from origins exactly on child-box planes (NaN plane distances)
+    load_golden_scene(renderer, "gally")
+    for run in json.loads((GOLDEN / "fuzz" / "axis_rays.json").read_text()):
+        eye = np.array([int(x, 16) for x in run["eye_words"]], dtype=np.uint32).view(np.float32)
+        renderer.set_uniforms(np.eye(4, dtype=np.float32).reshape(-1), eye)
+        img = render_frame(renderer, run["w"], run["h"], run["frame"], run["bounces"])
+        assert sha(img) == run["sample_sha256"], (run["node"], run["child"])
     for run in json.loads((GOLDEN / "fuzz" / "edge_uniforms.json").read_text()):
         load_golden_scene(renderer, run["scene"])
         f0, f1 = run["frames"]

@@ -270,3 +270,26 @@ def test_uniforms_at_the_edges_follow_the_reference_shader(scenes):
         for i, f in enumerate(range(f0, f1)):
             img = sc.render(run["w"], run["h"], f, run["bounces"])
             assert sha(img) == run["sha256_per_frame"][i], (run["scene"], run["bounces"], f)
+
+
+def _axis_ray_uniforms(run):
+    u = np.fromfile(GOLDEN / "gally" / "uniforms.bin", dtype=np.float32).copy()
+    u[0:16] = np.eye(4, dtype=np.float32).reshape(-1)  # every pixel gets the direction (0, 0, 1)
+    u[16:19] = np.array([int(x, 16) for x in run["eye_words"]], dtype=np.uint32).view(np.float32)
+    return u
+
+
+def test_axis_parallel_rays_from_box_planes_follow_the_reference_shader():
+    """Rays along +z whose origin lies exactly on planes of child boxes: the plane distance is
+    0 * inf = NaN there, and the outcome of min / max on a NaN decides whether the child is visited
+    (oracle/gen_out_of_range.py, reference shader on llvmpipe)."""
+    d = GOLDEN / "gally"
+    runs = json.loads((GOLDEN / "fuzz" / "axis_rays.json").read_text())
+    assert len(runs) >= 8 and sum(r["first_hits"] > 0 for r in runs) >= 6
+    for run in runs:
+        sc = O.OracleScene(bvh=(d / "bvh.bin").read_bytes(), tris=(d / "tris.bin").read_bytes(),
+                           spheres=(d / "spheres.bin").read_bytes(), mats=(d / "mats.bin").read_bytes(),
+                           uniforms=_axis_ray_uniforms(run))
+        img, aux = sc.render(run["w"], run["h"], run["frame"], run["bounces"], want_primary=True)
+        assert sha(img) == run["sample_sha256"], (run["node"], run["child"])
+        assert sha(aux[..., 0]) == run["primary_sha256"]["code"] and sha(aux[..., 1]) == run["primary_sha256"]["t_bits"]
