@@ -112,10 +112,33 @@ def main():
                     help="add cases whose materials lie far outside their meaningful ranges (ior 0, negative, 1e30, ...)")
     ap.add_argument("--odd-geometry", action="store_true",
                     help="add cases with degenerate primitives (zero-area quads, radius 0 and negative, coincident copies, ...)")
+    ap.add_argument("--accumulate", action="store_true",
+                    help="running mean over 6 frames of the odd-material cases (infinite and NaN samples in the accumulate pass)")
     ap.add_argument("--dense", action="store_true",
                     help="add the dense sphere / box cases after the existing ones instead of redrawing those")
     args = ap.parse_args()
     OUT.mkdir(parents=True, exist_ok=True)
+    if args.accumulate:
+        out = {}
+        for path in sorted(OUT.glob("case*.json")):
+            rec = json.loads(path.read_text())
+            if not any(m.get("ior") in (0.0, -1.5, 1e30, 1e-30) for m in rec["scene"]["materials"]):
+                continue
+            b = refscene.build_reference_scene(rec["scene"], [])
+            uni = np.array([int(x, 16) for x in rec["uniform_words"]], dtype=np.uint32).view(np.float32)
+            with tempfile.TemporaryDirectory(prefix="rtfuzz_") as td:
+                td = Path(td)
+                for key in ("mats", "spheres", "tris", "bvh", "boxes", "planes"):
+                    (td / f"{key}.bin").write_bytes(b[key])
+                uni.tofile(td / "uniforms.bin")
+                img, acc, _ = G.run_shader("color", td, W, H, rec["bounces"], 0, 6, args.threads, accumulate=True)
+            out[path.stem] = {"frames": [0, 6], "sample_sha256_per_frame": [G.sha(img[i]) for i in range(6)],
+                              "acc_sha256_per_frame": [G.sha(acc[i]) for i in range(6)],
+                              "nonfinite_samples": int((~np.isfinite(img)).sum()), "nonfinite_acc": int((~np.isfinite(acc)).sum()),
+                              "max_finite_sample": float(np.nanmax(np.where(np.isfinite(img), img, 0)))}
+            print(path.stem, out[path.stem]["nonfinite_samples"], out[path.stem]["nonfinite_acc"], out[path.stem]["max_finite_sample"], flush=True)
+        (OUT / "odd_accumulate.json").write_text(json.dumps(out, indent=1))
+        return
     if args.odd_materials:
         first = len(sorted(OUT.glob("case*.json")))
         firsts = dict(np.load(OUT / "first_frames.npz"))

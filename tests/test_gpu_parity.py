@@ -269,7 +269,7 @@ def test_bench_workload_matches_reference_shader(renderer):
 
 
 def test_random_scenes_match_reference_shader(renderer):
-    """32 random scenes pinned on llvmpipe: colour frames, first-hit ids and distances."""
+    """44 random scenes pinned on llvmpipe: colour frames, first-hit ids and distances."""
     from util import fuzz_buffers, fuzz_cases
 
     first = np.load(GOLDEN / "fuzz" / "first_frames.npz")
@@ -291,6 +291,18 @@ def test_random_scenes_match_reference_shader(renderer):
                         and np.array_equal(exists, aux[..., 2])):
                     bad.append((path.name, f, "first hit"))
     assert not bad, bad
+    # the running mean over six frames of the cases whose samples reach far beyond 1
+    for name, acc_rec in json.loads((GOLDEN / "fuzz" / "odd_accumulate.json").read_text()).items():
+        rec = json.loads((GOLDEN / "fuzz" / f"{name}.json").read_text())
+        b, u = fuzz_buffers(rec)
+        b.upload(renderer)
+        renderer.set_uniforms(u[0:16], u[16:19])
+        renderer.update_size(rec["w"], rec["h"])
+        renderer.reset_accumulation()
+        for f in range(*acc_rec["frames"]):
+            img = render_frame(renderer, rec["w"], rec["h"], f, rec["bounces"])
+            assert sha(img) == acc_rec["sample_sha256_per_frame"][f], (name, f)
+            assert sha(renderer.read_accumulation()) == acc_rec["acc_sha256_per_frame"][f], (name, f)
 
 
 def test_edge_sizes_and_truncated_dispatch(renderer):

@@ -293,3 +293,23 @@ def test_axis_parallel_rays_from_box_planes_follow_the_reference_shader():
         img, aux = sc.render(run["w"], run["h"], run["frame"], run["bounces"], want_primary=True)
         assert sha(img) == run["sample_sha256"], (run["node"], run["child"])
         assert sha(aux[..., 0]) == run["primary_sha256"]["code"] and sha(aux[..., 1]) == run["primary_sha256"]["t_bits"]
+
+
+def test_running_mean_of_out_of_range_samples():
+    """The accumulate pass on the fuzz cases with materials far outside their ranges, whose samples
+    reach well beyond 1 (up to 17.7): six frames of the reference's own screen shaders on llvmpipe."""
+    from util import fuzz_buffers
+
+    recs = json.loads((GOLDEN / "fuzz" / "odd_accumulate.json").read_text())
+    assert len(recs) >= 4
+    for name, acc_rec in recs.items():
+        rec = json.loads((GOLDEN / "fuzz" / f"{name}.json").read_text())
+        b, u = fuzz_buffers(rec)
+        sc = O.OracleScene(bvh=b.bvh.tobytes(), tris=b.triangles.tobytes(), spheres=b.spheres.tobytes(),
+                           mats=b.materials.tobytes(), boxes=b.boxes.tobytes(), planes=b.planes.tobytes(), uniforms=u)
+        acc = np.zeros((rec["h"], rec["w"], 4), np.float32)
+        for f in range(*acc_rec["frames"]):
+            smp = sc.render(rec["w"], rec["h"], f, rec["bounces"])
+            assert sha(smp) == acc_rec["sample_sha256_per_frame"][f], (name, f)
+            acc = O.accumulate(smp, acc, f)
+            assert sha(acc) == acc_rec["acc_sha256_per_frame"][f], (name, f)
