@@ -114,10 +114,27 @@ def main():
                     help="add cases with degenerate primitives (zero-area quads, radius 0 and negative, coincident copies, ...)")
     ap.add_argument("--accumulate", action="store_true",
                     help="running mean over 6 frames of the odd-material cases (infinite and NaN samples in the accumulate pass)")
+    ap.add_argument("--tiny", action="store_true",
+                    help="add scenes of one, two and three primitives (the one-primitive tree has an all-empty root)")
     ap.add_argument("--dense", action="store_true",
                     help="add the dense sphere / box cases after the existing ones instead of redrawing those")
     args = ap.parse_args()
     OUT.mkdir(parents=True, exist_ok=True)
+    if args.tiny:
+        first = len(sorted(OUT.glob("case*.json")))
+        firsts = dict(np.load(OUT / "first_frames.npz"))
+        rng = np.random.default_rng(args.seed + 4)
+        for k, n in enumerate((1, 2, 3, 5)):
+            case = first + k
+            scene, cam = random_scene(rng, case)
+            scene["quads"], scene["boxes"] = [], []
+            scene["spheres"] = [{"center": r3(rng, -2, 2), "radius": round(float(rng.uniform(0.5, 1.5)), 3), "material": i % len(scene["materials"])}
+                                for i in range(n)]
+            scene["planes"] = [{"point": [0.0, -2.0, 0.0], "normal": [0.0, 1.0, 0.0], "material": 0}]
+            cam = {"position": [0.0, 0.5, 7.0], "yaw": 270.0, "pitch": 0.0}
+            write_case(case, scene, cam, 4, firsts, args.threads)
+        np.savez_compressed(OUT / "first_frames.npz", **firsts)
+        return
     if args.accumulate:
         out = {}
         for path in sorted(OUT.glob("case*.json")):

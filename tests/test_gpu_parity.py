@@ -269,7 +269,7 @@ def test_bench_workload_matches_reference_shader(renderer):
 
 
 def test_random_scenes_match_reference_shader(renderer):
-    """44 random scenes pinned on llvmpipe: colour frames, first-hit ids and distances."""
+    """48 random scenes pinned on llvmpipe: colour frames, first-hit ids and distances."""
     from util import fuzz_buffers, fuzz_cases
 
     first = np.load(GOLDEN / "fuzz" / "first_frames.npz")

@@ -199,7 +199,7 @@ def test_bench_workload_first_frame():
 
 
 def test_random_scenes_bit_exact():
-    """44 random scenes (spheres, quads, boxes, planes, materials over their whole ranges, cameras
+    """48 random scenes (spheres, quads, boxes, planes, materials over their whole ranges, cameras
     anywhere) rendered by the reference shader on llvmpipe: host pipeline bytes, three colour
     frames, first-hit ids and distances."""
     from util import fuzz_buffers, fuzz_cases
