@@ -9,12 +9,15 @@ camera.  `models/sponza_full.obj` is not distributed with the reference, so the 
 stand-in `sponza_synth` (about 265 k triangles, raytracer_amd/synth.py) is rendered unless
 --obj names a model; the JSON line says which.
 
-c4, one GPU: a step is one reference frame -- the compute dispatch plus the accumulate pass
-(`rt_render`, what `Renderer.render()` does).  The same loop in linear-sum mode (`rt_render_sum`,
-what multi-GPU runs use) is timed too and reported under `sum_mode`.
-c4, N GPUs: one process per GPU; rank r renders the frames f with f % N == r (samples-per-pixel
-sharding, scene replicated) into its own fp32 linear-radiance sum image; the images are combined
-with one RCCL reduce inside the timed region.  Per-GPU work is fixed: weak scaling.
+c4: one process per GPU; rank r renders the frames f with f % N == r (samples-per-pixel sharding,
+scene replicated) into its own fp32 linear-radiance sum image (`rt_render_sum`); the timed region
+holds the K steps (one frame per GPU each), the combine (one RCCL reduce, warmed up beforehand;
+nothing to do at one GPU) and rank 0's finalise pass that turns the sum into the sRGB mean image.
+The step is the same at every N, so values are comparable across N; per-GPU work is fixed: weak
+scaling.  At one GPU the reference's own frame (`rt_render`: compute dispatch + accumulate pass,
+what `Renderer.render()` does) is timed by the same loop too and reported as `reference_frame`.
+After the K steps the same step runs for about two seconds more (`sustained`), with the shader
+clock the kernel itself measured.
 
 `--config c5` (strong scaling): one 3840x2160 image of 256 samples per pixel, split over the
 ranks by image tiles AND by samples; a step is the whole image, timed from the first launch to
@@ -98,7 +101,10 @@ def cpu_baseline(bufs, cam_uniforms, width, height, bounces, threads, budget_s):
 def roofline_block(name, args, kernel_ms, rays_per_launch, per_ray):
     """Roofline of the dominant kernel.  `achieved` / `frac` follow the metric's definition
     (algorithmic bytes in the reference's layouts / kernel time / HBM peak): a bytes-per-ray proxy,
-    most of which is served by LDS, L1 and L2.  `binding` says what the hardware counters show."""
+    most of which is served by LDS, L1 and L2, so it is not bounded by 1 and is not HBM utilisation.
+    What the hardware counters show sits next to it: `hbm_counter_frac` (memory-side bytes / time /
+    HBM peak), `td_busy` and `vmem_frac` (the CU's vector-memory return path, which is what binds),
+    `l2_hit`; `binding` holds the rest."""
     n_node, n_tri, n_sph, hit_frac, rays_per_sample = per_ray
     # algorithmic bytes per ray in the reference's layouts: 64 B per node visit, 64 B per triangle
     # test, 32 B per sphere test, 12 B of material per hit, 16 B of image per pixel-sample
@@ -106,8 +112,10 @@ def roofline_block(name, args, kernel_ms, rays_per_launch, per_ray):
     achieved = rays_per_launch * bytes_per_ray / (kernel_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-           "frac_is": "algorithmic bytes (reference layouts) / kernel time / HBM peak; NOT the share of HBM "
-                      "bandwidth in use: see binding.hbm_counter_frac",
+           "frac_is": "algorithmic bytes (reference layouts) / kernel time / HBM peak: the metric's bytes-per-ray proxy, "
+                      "NOT the share of HBM bandwidth in use (that is hbm_counter_frac) and not bounded by 1; the "
+                      "resource that binds is binding_resource",
+           "binding_resource": None, "hbm_counter_frac": None, "td_busy": None, "vmem_frac": None, "l2_hit": None,
            "algorithmic_bytes_per_launch": rays_per_launch * bytes_per_ray,
            "kernel": "trace_kernel", "kernel_ms": kernel_ms,
            "kernel_ms_how": "HIP events on the launch's stream, launches issued one at a time after the timed "
@@ -129,15 +137,25 @@ def roofline_block(name, args, kernel_ms, rays_per_launch, per_ray):
             cycles = c["GRBM_GUI_ACTIVE"] / 8.0           # the counter is summed over the 8 XCDs
             simds, cus = 1024.0, 256.0
             issue = t.get("valu_issue_cycles", 2.0)       # cycles one wave64 VALU instruction holds a SIMD's issue port
+            vmem_insts = c.get("SQ_INSTS_VMEM_RD", 0.0) + c.get("SQ_INSTS_VMEM_WR", 0.0)
+            out["binding_resource"] = "vector-memory return path of the CU (texture-data unit): td_busy"
+            out["hbm_counter_frac"] = traffic / (pmc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["td_busy"] = c["TD_TD_BUSY_sum"] / (cus * cycles) if "TD_TD_BUSY_sum" in c else None
+            # a vector-memory wave-instruction of 8 to 16 bytes per lane holds the CU's data-return path
+            # for 16 cycles whatever its active lanes (tools/microbench/vmem_mask.hip)
+            out["vmem_frac"] = vmem_insts * 16.0 / (cus * cycles) if vmem_insts else None
+            out["l2_hit"] = c["TCC_HIT_sum"] / c["TCC_REQ_sum"] if c.get("TCC_REQ_sum") else None
             out["binding"] = {
                 "source": str(PMC_FILE.relative_to(ROOT)),
                 "hbm_counter_GBs": traffic / (pmc_ms * 1e-3) / 1e9,
-                "hbm_counter_frac": traffic / (pmc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "hbm_counter_frac": out["hbm_counter_frac"],
                 "valu_busy": c["SQ_INSTS_VALU"] * issue / (simds * cycles),
                 "valu_lane_util": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]),
                 # the vector-memory path: texture-address and texture-data units, one of each per CU
                 "vmem_issue": c["TA_TA_BUSY_sum"] / (cus * cycles) if "TA_TA_BUSY_sum" in c else None,
-                "vmem_data_return": c["TD_TD_BUSY_sum"] / (cus * cycles) if "TD_TD_BUSY_sum" in c else None,
+                "vmem_data_return": out["td_busy"],
+                "vmem_wave_instructions": vmem_insts or None,
+                "td_waiting_for_cache": c["TD_TC_STALL_sum"] / (cus * cycles) if "TD_TC_STALL_sum" in c else None,
                 "binds": "vector-memory path (texture-data unit)",
                 "l1_lookups_per_clk_per_cu": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (cus * cycles),
                 "waves_per_simd": c["SQ_WAVE_CYCLES"] * 4.0 / (simds * cycles),
@@ -146,10 +164,28 @@ def roofline_block(name, args, kernel_ms, rays_per_launch, per_ray):
     return out
 
 
-def run_c4(args, r, comm, rank, world, name, bufs, build_s, rehearse):
-    """1080p frames: `rt_render` at one GPU, spp-sharded `rt_render_sum` + one reduce at N GPUs."""
-    from raytracer_amd.camera import Camera
+def pci_to_number(bus_id: str) -> float:
+    """'0000:05:00.0' -> one exactly representable number (domain, bus, device, function packed)."""
+    try:
+        dom, bus, rest = bus_id.strip().split(":")
+        dev, fn = rest.split(".")
+        return float((int(dom, 16) << 16) | (int(bus, 16) << 8) | (int(dev, 16) << 3) | int(fn, 16))
+    except ValueError:
+        return -1.0
 
+
+def number_to_pci(v: float) -> str:
+    n = int(v)
+    if n < 0:
+        return "unknown"
+    return f"{n >> 16:04x}:{(n >> 8) & 0xFF:02x}:{(n >> 3) & 0x1F:02x}.{n & 7:x}"
+
+
+def run_c4(args, r, comm, rank, world, name, bufs, build_s, rehearse):
+    """1080p frames.  The timed step is the same at every GPU count: each GPU renders its frames in
+    linear-sum mode (`rt_render_sum`), then the images are combined (one RCCL reduce, N > 1) and
+    rank 0 finalises the mean image -- all inside the timed region.  At one GPU the reference's own
+    frame (`rt_render`: compute dispatch + accumulate pass) is timed too and reported as `reference_frame`."""
     variant, _ = r.traversal_variant()   # timed by the library during the settle step
     npix = args.width * args.height
     # per-ray work of this workload, from one untimed instrumented frame (counter kernel variant)
@@ -162,9 +198,24 @@ def run_c4(args, r, comm, rank, world, name, bufs, build_s, rehearse):
     rays0 = max(1, s0["rays"])
     per_ray = (s0["nodes"] / rays0, s0["tri_tests"] / rays0, s0["sphere_tests"] / rays0, s0["hits"] / rays0,
                rays0 / npix)
+    max_stack = int(s0["max_stack"])
     r.set_flags()
 
-    def timed_loop(step):
+    # The image reduce, twice, on a cleared image, before anything is timed: the first full-size
+    # collective sets up RCCL's channels and buffers (tens of milliseconds), which must not land in
+    # a timed region that is itself only tens of milliseconds long.
+    reduce_warmup_ms = []
+    for _ in range(2):
+        r.clear_sum()
+        r.sync()
+        comm.barrier()
+        t = time.perf_counter()
+        comm.reduce_sum_image(0)
+        reduce_warmup_ms.append((time.perf_counter() - t) * 1e3)
+
+    def timed_loop(step, steps, combine):
+        """`steps` steps between barriers; with `combine` the reduce to rank 0 and rank 0's finalise
+        pass are part of the timed region.  Returns (seconds, rays, reduce seconds, shader clock GHz)."""
         for i in range(args.warmup):
             step(i)
         r.sync()
@@ -174,14 +225,20 @@ def run_c4(args, r, comm, rank, world, name, bufs, build_s, rehearse):
         r.sync()
         comm.barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(steps):
             step(i)
         r.sync()
-        comm.reduce_sum_image(0)       # RCCL over xGMI, once per run (nothing to do at one GPU)
+        t_reduce = 0.0
+        if combine:
+            t1 = time.perf_counter()
+            comm.reduce_sum_image(0)       # RCCL over xGMI, once per run (nothing to do at one GPU)
+            t_reduce = time.perf_counter() - t1
+            if rank == 0:
+                r.finalize_sum(steps * world)
+                r.sync()
         comm.barrier()
         elapsed = time.perf_counter() - t0
-        rays = float(r.stats()["rays"])
-        return elapsed, rays
+        return elapsed, float(r.stats()["rays"]), t_reduce, r.shader_clock_ghz()
 
     def sum_step(i):
         r.render_sum(first_frame=i * world + rank, nframes=1)   # this rank's i-th frame under spp sharding
@@ -190,15 +247,14 @@ def run_c4(args, r, comm, rank, world, name, bufs, build_s, rehearse):
         r.set_frame_index(i)
         r.render()                                              # dispatch + accumulate pass
 
-    sum_elapsed, sum_rays = timed_loop(sum_step)
-    if rank == 0:
-        r.finalize_sum(args.steps * world)
-        r.sync()
+    elapsed, rays, reduce_s, clock_short = timed_loop(sum_step, args.steps, True)
+    ref_frame = None
     if world == 1:
         r.reset_accumulation()
-        elapsed, rays = timed_loop(frame_step)
-    else:
-        elapsed, rays = sum_elapsed, sum_rays
+        f_elapsed, f_rays, _, _ = timed_loop(frame_step, args.steps, False)
+        ref_frame = {"value": f_rays / f_elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": f_elapsed / args.steps * 1e3,
+                     "what": "the reference's own frame, rt_render: compute dispatch writing the sRGB sample + the "
+                             "accumulate pass (renderer.py:241-288), same loop and barriers"}
 
     # device time of the dominant kernel, measured with HIP events on the library's own stream:
     # single launches, one at a time, outside the wall-clock region
@@ -210,6 +266,23 @@ def run_c4(args, r, comm, rank, world, name, bufs, build_s, rehearse):
         ev_ms.append(r.stats()["last_trace_ms"])
     kernel_ms = float(np.mean(ev_ms))
     rays_per_launch = r.stats()["rays"] / len(ev_ms)
+
+    # sustained leg: the same step for about args.sustain_seconds, so that the line also holds a
+    # figure a power or thermal limit has had time to act on, with the clock the kernel ran at
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_sus = int(min(20000, max(args.steps, np.ceil(args.sustain_seconds / max(elapsed / args.steps, 1e-6)))))
+        n_sus = int(comm.all_reduce([float(n_sus)], "max")[0])   # the same count on every rank
+        s_elapsed, s_rays, s_reduce, clock_sus = timed_loop(sum_step, n_sus, True)
+        s_tmax = comm.all_reduce([s_elapsed], "max")[0]
+        s_rsum = comm.all_reduce([s_rays], "sum")[0]
+        sustained = {"value": s_rsum / s_tmax / 1e6, "unit": "Mrays/s", "ms_per_step": s_tmax / n_sus * 1e3,
+                     "frames": n_sus * world, "steps": n_sus, "seconds": s_tmax,
+                     "shader_clock_GHz": {"timed_steps": clock_short, "sustained": clock_sus},
+                     "what": "the timed step repeated for about %g s (reduce and finalise included once); the clock is "
+                             "what the trace kernel's own wavefronts measured (cycle counter / 100 MHz counter)"
+                             % args.sustain_seconds}
+    overflows = float(r.stats()["stack_overflows"])
 
     # the opt-in fast mode (own tree, free traversal order: NOT the reference's algorithm, never the
     # headline) on the same workload, reported separately
@@ -224,58 +297,82 @@ def run_c4(args, r, comm, rank, world, name, bufs, build_s, rehearse):
             r.sync()
             fs = r.stats()
             r.set_flags()
-            f_elapsed, f_rays = timed_loop(frame_step)
+            q_elapsed, q_rays, _, _ = timed_loop(sum_step, args.steps, True)
             r.reset_stats()
             f_ev = []
             for i in range(min(args.steps, 10)):
                 r.render_sum(first_frame=i, nframes=1)
                 r.sync()
                 f_ev.append(r.stats()["last_trace_ms"])
-            fast = {"value": f_rays / f_elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": f_elapsed / args.steps * 1e3,
+            fast = {"value": q_rays / q_elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": q_elapsed / args.steps * 1e3,
                     "kernel_ms": float(np.mean(f_ev)),
                     "node_visits_per_ray": fs["nodes"] / max(1, fs["rays"]),
                     "triangle_tests_per_ray": fs["tri_tests"] / max(1, fs["rays"]),
-                    "what": "opt-in, default off, not the reference's data: the library's own tree (all-axis SAH, "
-                            "conservative 8-bit child boxes, 64-byte nodes) under the same traversal rules; same step as "
-                            "the headline (rt_render). Results differ from the reference where its tree decides which "
-                            "hit is found (tests/test_gpu_fast_mode.py counts them)"}
+                    "what": "opt-in, default off, not the reference's data: the library's own tree under its own "
+                            "traversal order; same timed step as the headline. Results differ from the reference where "
+                            "its tree decides which hit is found (tests/test_gpu_fast_mode.py counts them)"}
         finally:
             r.fast_mode = False
 
-    tmax = comm.all_reduce([elapsed, sum_elapsed], "max")
-    tsum = comm.all_reduce([rays, sum_rays], "sum")
+    tmax = comm.all_reduce([elapsed, reduce_s], "max")
+    tsum = comm.all_reduce([rays], "sum")
+    dev, pci = r.device_info()
+    crank, cranks = comm.info()
+    per = comm.gather([float(dev), pci_to_number(pci), elapsed * 1e3, reduce_s * 1e3, clock_short, overflows,
+                       float(crank)])
     if rank != 0:
         return None
+    meas = {"elapsed": tmax[0], "rays": tsum[0], "reduce_ms_max": tmax[1] * 1e3, "reduce_warmup_ms": reduce_warmup_ms,
+            "per_rank": per, "rccl_ranks": cranks, "ref_frame": ref_frame, "sustained": sustained, "fast": fast,
+            "kernel_ms": kernel_ms, "rays_per_launch": rays_per_launch, "per_ray": per_ray, "variant": variant,
+            "max_stack": max_stack, "build_s": build_s}
+    out = assemble_c4(args, world, name, int(bufs.triangles.shape[0]), int(bufs.bvh.shape[0]), rehearse, meas)
+    if not args.no_cpu_baseline and world == 1:
+        from raytracer_amd.camera import Camera
+
+        threads = min(16, os.cpu_count() or 1)
+        out["cpu_baseline"] = cpu_baseline(bufs, Camera().uniforms_f32(), args.width, args.height, args.bounces,
+                                           threads, args.cpu_seconds)
+    return out
+
+
+def assemble_c4(args, world, name, n_tris, n_nodes, rehearse, m):
+    """The JSON line of a c4 run from rank 0's measurements (no GPU involved: testable on its own)."""
+    per = np.asarray(m["per_rank"], dtype=np.float64).reshape(world, -1)
+    steps = args.steps
     out = {
-        "metric": "Mrays/s", "value": tsum[0] / tmax[0] / 1e6, "unit": "Mrays/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": tmax[0] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "metric": "Mrays/s", "value": m["rays"] / m["elapsed"] / 1e6, "unit": "Mrays/s",
+        "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": m["elapsed"] / steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32",
         "data": "synthetic" if not rehearse else "synthetic; REHEARSAL on one shared GPU with host-file collectives, not a measurement",
         "config": {"workload": f"{name} {args.width}x{args.height} 1spp/frame {args.bounces} bounces, "
                                f"default reference camera; stands in for sponza_full.obj (not distributed)",
-                   "step": ("one reference frame: compute dispatch + accumulate pass (rt_render)" if world == 1 else
-                            "one frame per GPU in linear-sum mode (rt_render_sum); one RCCL reduce per run, inside the timed region"),
-                   "triangles": int(bufs.triangles.shape[0]), "bvh_nodes": int(bufs.bvh.shape[0]),
-                   "rays_per_frame": rays_per_launch, "frames_per_step_per_gpu": 1,
+                   "step": "one frame per GPU: compute dispatch accumulating linear radiance (rt_render_sum); the timed "
+                           "region ends with the image combine (one RCCL reduce when n_gpus > 1) and rank 0's "
+                           "finalise pass (sRGB mean image) -- the same step at every n_gpus",
+                   "triangles": n_tris, "bvh_nodes": n_nodes,
+                   "rays_per_frame": m["rays_per_launch"], "frames_per_step_per_gpu": 1,
                    "parallelism": f"spp-sharded x{world}, scene replicated, 1 RCCL reduce (C ABI)" if world > 1 else "single GPU",
-                   "bvh_build_s": round(build_s, 3)},
-        "ms_per_frame": tmax[0] / args.steps * 1e3,
-        "sum_mode": {"value": tsum[1] / tmax[1] / 1e6, "unit": "Mrays/s", "ms_per_step": tmax[1] / args.steps * 1e3,
-                     "what": "the same loop through rt_render_sum (linear radiance sum, no sRGB encode, no accumulate "
-                             "pass): the per-GPU step of the multi-GPU runs, comparable across n_gpus"},
-        "roofline": dict(roofline_block(name, args, kernel_ms, rays_per_launch, per_ray),
-                         kernel="trace_leafstep_kernel" if variant == "leaf steps" else "trace_kernel",
-                         traversal_variant=variant),
+                   "bvh_build_s": round(m["build_s"], 3)},
+        "ms_per_frame": m["elapsed"] / steps * 1e3 / world,
+        "reduce_ms": m["reduce_ms_max"],
+        "reduce_warmup_ms": m["reduce_warmup_ms"],
+        "rccl_ranks": m["rccl_ranks"],
+        "ranks": [{"rank": k, "comm_rank": int(per[k, 6]), "device": int(per[k, 0]), "pci_bus_id": number_to_pci(per[k, 1]),
+                   "timed_region_ms": per[k, 2], "reduce_ms": per[k, 3], "shader_clock_GHz": per[k, 4],
+                   "stack_overflows": int(per[k, 5])} for k in range(world)],
+        "stack_overflows": int(per[:, 5].sum()),
+        "max_stack": m["max_stack"],
+        "sustained": m["sustained"],
+        "reference_frame": m["ref_frame"],
+        "roofline": dict(roofline_block(name, args, m["kernel_ms"], m["rays_per_launch"], m["per_ray"]),
+                         kernel="trace_leafstep_kernel" if m["variant"] == "leaf steps" else "trace_kernel",
+                         traversal_variant=m["variant"]),
+        "cpu_baseline": None,
     }
     if world == 1:
-        out["fast_mode"] = fast
-    if not args.no_cpu_baseline and world == 1:
-        threads = min(16, os.cpu_count() or 1)
-        out["cpu_baseline"] = cpu_baseline(bufs, Camera().uniforms_f32(), args.width, args.height, args.bounces,
-                                           threads, args.cpu_seconds)
-    else:
-        out["cpu_baseline"] = None
+        out["fast_mode"] = m["fast"]
     return out
 
 
@@ -323,7 +420,10 @@ def run_c5(args, r, comm, rank, world, name, bufs, build_s, rehearse):
     my_render = float(np.mean(renders))
     tmax = comm.all_reduce([elapsed, my_render], "max")
     tsum = comm.all_reduce([rays, my_render], "sum")
-    per_rank = comm.all_reduce([my_render * 1e3 if k == rank else 0.0 for k in range(world)], "sum")
+    dev, pci = r.device_info()
+    crank, cranks = comm.info()
+    per = comm.gather([float(dev), pci_to_number(pci), my_render * 1e3, float(np.mean(reduces)) * 1e3,
+                       r.shader_clock_ghz(), float(r.stats()["stack_overflows"]), float(crank)])
     if rank != 0:
         return None
     return {
@@ -340,8 +440,14 @@ def run_c5(args, r, comm, rank, world, name, bufs, build_s, rehearse):
                                   f"replicated, 1 RCCL reduce (C ABI) per image",
                    "bvh_build_s": round(build_s, 3)},
         "time_to_image_ms": tmax[0] / args.steps * 1e3,
-        "per_rank_render_ms": [float(x) for x in per_rank],
+        "per_rank_render_ms": [float(x) for x in per[:, 2]],
+        "reduce_ms": float(per[:, 3].max()),
         "reduce_ms_rank0": float(np.mean(reduces)) * 1e3,
+        "rccl_ranks": cranks,
+        "ranks": [{"rank": k, "comm_rank": int(per[k, 6]), "device": int(per[k, 0]), "pci_bus_id": number_to_pci(per[k, 1]),
+                   "render_ms": per[k, 2], "reduce_ms": per[k, 3], "shader_clock_GHz": per[k, 4],
+                   "stack_overflows": int(per[k, 5])} for k in range(world)],
+        "stack_overflows": int(per[:, 5].sum()),
         "imbalance_max_over_mean": float(tmax[1] / (tsum[1] / world)),
         "roofline": None, "cpu_baseline": None,
     }
@@ -356,6 +462,8 @@ def worker(args):
     # RT_BENCH_REHEARSE=1: every rank uses GPU 0 and the collectives go through host files.
     # For rehearsing the N>1 control flow on a one-GPU box; never a measurement.
     rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
+    # the host driver only supports dmabuf IPC; RCCL's peer buffers need this set before HIP starts
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     from raytracer_amd import dist as D
     from raytracer_amd.camera import Camera
@@ -412,6 +520,8 @@ def main():
     ap.add_argument("--obj", default=None, help="render this OBJ (e.g. sponza_full.obj) instead of sponza_synth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the CPU baseline sample")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="c4: length of the sustained leg after the timed steps (0 = none)")
     args = ap.parse_args()
     c5 = args.config == "c5"
     if args.steps is None:

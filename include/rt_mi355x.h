@@ -68,10 +68,16 @@ int rt_destroy(rt_ctx *ctx);
 const char *rt_last_error(void);
 
 /* Renderer.update_size (renderer.py:347-382): reallocates the three images, contents zeroed.
- * Deviation: the accumulated-frame count returns to 0 here, whereas the reference's update_size
- * leaves `rendered_frames` alone (its next frame is blended into the fresh, black texture with
- * weight 1/(N+1)).  A caller that keeps its own counter must reset it after a resize. */
+ * As in the reference, the accumulated-frame count is left alone: with N frames accumulated, the
+ * next frame is blended into the fresh, black accumulation image with weight 1/(N+1).  A host
+ * that wants a clean start after a resize calls rt_set_rendered_frames(ctx, 0) (or
+ * rt_reset_accumulation after its next frame). */
 int rt_resize(rt_ctx *ctx, int width, int height);
+
+/* Renderer.rendered_frames is a plain attribute the host may assign (renderer.py:106); render()
+ * sends it as the `frames` uniform of the accumulate pass (renderer.py:255-257).  This sets the
+ * count the next rt_render starts from. */
+int rt_set_rendered_frames(rt_ctx *ctx, uint32_t frames);
 
 /* Renderer.update_ssbo (renderer.py:308-324): copies `nbytes` of host data into the buffer
  * for `binding`, replacing it wholesale.  The caller keeps ownership of `data`.  `nbytes` must be a
@@ -190,6 +196,20 @@ int rt_fast_bvh_export(rt_ctx *ctx, void *nodes, size_t nodes_bytes);
  * environment at rt_create fixes the variant and skips the timing.
  */
 int rt_traversal_variant(rt_ctx *ctx, int *leaf_steps, int *decided);
+/* The same choice per context instead of through the environment: variant 0 = the unified step,
+ * 1 = leaf steps of their own, either of which also switches the four timing launches off (an
+ * interactive host that must not see a one-off spike of about four frame times at its 65th frame
+ * calls this once); -1 = back to the automatic choice. */
+int rt_set_traversal_variant(rt_ctx *ctx, int variant);
+
+/* Diagnostics with no counterpart in the reference.
+ * rt_device_info: the HIP device ordinal the context is bound to and its PCI bus id
+ * ("0000:05:00.0"; `pci_bus_id` must hold at least 16 bytes).
+ * rt_shader_clock: the shader clock in GHz the megakernel's wavefronts ran at since the last
+ * rt_reset_stats, measured by the kernel itself (a few wavefronts per launch compare the shader
+ * cycle counter with the constant 100 MHz counter over their lifetime); 0 if nothing was sampled. */
+int rt_device_info(rt_ctx *ctx, int *device, char *pci_bus_id, size_t pci_bus_id_bytes);
+int rt_shader_clock(rt_ctx *ctx, double *ghz);
 
 /*
  * Collectives for multi-GPU runs: one process per GPU, RCCL over xGMI, no framework needed (no
@@ -211,6 +231,8 @@ int rt_comm_init(rt_ctx *ctx, int rank, int world, const char id[RT_COMM_ID_BYTE
 int rt_comm_reduce_sum(rt_ctx *ctx, float *sum_rgba, int root);
 int rt_comm_all_reduce_f64(rt_ctx *ctx, double *values, int count, int op);
 int rt_comm_barrier(rt_ctx *ctx);
+/* what the communicator itself reports: this rank's index in it and the number of ranks it spans */
+int rt_comm_info(rt_ctx *ctx, int *rank, int *nranks);
 
 /*
  * One frame without any allocation.  No counterpart in the reference; it is for callers that

@@ -46,9 +46,10 @@ def sha(a: np.ndarray | bytes) -> str:
     return hashlib.sha256(b).hexdigest()
 
 
-def run_shader(kind, sdir: Path, w, h, bounces, f0, f1, threads, reps=1, accumulate=False):
+def run_shader(kind, sdir: Path, w, h, bounces, f0, f1, threads, reps=1, accumulate=False, recreate_at=None):
     """kind: a refscene.shader_variant name, or ("capture", bounce, expr).
-    accumulate: also run the reference's screen shaders after every frame; returns (img, acc, info)."""
+    accumulate: also run the reference's screen shaders after every frame; returns (img, acc, info).
+    recreate_at: the textures are recreated before that frame, as Renderer.update_size does."""
     with tempfile.TemporaryDirectory(prefix="rtgold_") as td:
         sp = Path(td) / "variant.glsl"
         if isinstance(kind, tuple):
@@ -63,6 +64,8 @@ def run_shader(kind, sdir: Path, w, h, bounces, f0, f1, threads, reps=1, accumul
         if accumulate:
             cmd += ["--screen-vs", str(REF / "shaders" / "screen_vertex.glsl"),
                     "--screen-fs", str(REF / "shaders" / "screen_fragment.glsl"), "--acc-out", str(acc_out)]
+            if recreate_at is not None:
+                cmd += ["--recreate-at", str(recreate_at)]
         for flag, name in (("--bvh", "bvh.bin"), ("--tris", "tris.bin"), ("--spheres", "spheres.bin"),
                            ("--mats", "mats.bin"), ("--boxes", "boxes.bin"), ("--planes", "planes.bin")):
             if (sdir / name).exists() and (sdir / name).stat().st_size:
@@ -147,12 +150,15 @@ def golden_state(sdir: Path, tag, w, h, bounces, frame, threads, capture_bounces
          "exprs": STATE_EXPRS}, indent=1))
 
 
-def golden_accumulation(sdir: Path, tag, w, h, bounces, nframes, threads, keep=(0, 1)):
+def golden_accumulation(sdir: Path, tag, w, h, bounces, nframes, threads, keep=(0, 1), recreate_at=None):
     """The reference's running mean (screen_fragment.glsl:94-108 driven as renderer.py:249-288 drives
-    it) after each of nframes frames: hashes of all, full images of the frames in `keep` and the last."""
-    img, acc, _ = run_shader("color", sdir, w, h, bounces, 0, nframes, threads, accumulate=True)
+    it) after each of nframes frames: hashes of all, full images of the frames in `keep` and the last.
+    recreate_at: Renderer.update_size (same size) is called before that frame (renderer.py:347-382)."""
+    img, acc, _ = run_shader("color", sdir, w, h, bounces, 0, nframes, threads, accumulate=True,
+                             recreate_at=recreate_at)
     keep = sorted(set(keep) | {nframes - 1})
     rec = {"w": w, "h": h, "bounces": bounces, "frames": [0, nframes], "kept": keep,
+           **({"update_size_before_frame": recreate_at} if recreate_at is not None else {}),
            "sample_sha256_per_frame": [sha(img[i]) for i in range(nframes)],
            "acc_sha256_per_frame": [sha(acc[i]) for i in range(nframes)]}
     np.savez_compressed(sdir / f"{tag}.acc.npz", **{f"acc{i}": acc[i] for i in keep})
@@ -296,6 +302,15 @@ def main():
     if want("accum"):
         for name in ("debug", "gally"):
             golden_accumulation(GOLD / name, "accum_160x88_b4", 160, 88, 4, 12, T)
+    if want("ssbo_args"):
+        # what the reference loader passes to Renderer.update_ssbo, dtype and shape included
+        # (structured records; spheres and triangles arrive as (n, 1) arrays: scene.py:121,191)
+        b = refscene.build_reference_scene(tomli.loads(debug_toml), [])
+        np.savez(GOLD / "debug" / "update_ssbo_args.npz", **b["update_ssbo_args"])
+    if want("resize"):
+        # Renderer.update_size in the middle of an accumulation: five frames, the textures recreated,
+        # three more frames -- frame 5 is blended into the new (black) texture with weight 1/6
+        golden_accumulation(GOLD / "gally", "resize_160x88_b4", 160, 88, 4, 8, T, keep=(4, 5), recreate_at=5)
     if want("prims"):
         s = write_scene("prims", prims_toml(), [])
         golden_frames(s, "small_160x88_b5", 160, 88, 5, 0, 2, T, store_full=True, kinds=("color", "primary", "counters"))

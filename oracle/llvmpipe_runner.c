@@ -16,7 +16,7 @@
  *   llvmpipe_runner --shader S.glsl --w W --h H --bounces B --frames F0 F1
  *       --uniforms U.bin [--bvh f] [--tris f] [--spheres f] [--mats f]
  *       [--planes f] [--boxes f] --out OUT.bin [--reps R]
- *       [--screen-vs V.glsl --screen-fs F.glsl --acc-out ACC.bin]
+ *       [--screen-vs V.glsl --screen-fs F.glsl --acc-out ACC.bin [--recreate-at F]]
  * U.bin: 25 little-endian f32: inverse_view_projection[16] (memory order, sent
  * untransposed), eye[3], scene_min[3], scene_extent[3].
  * OUT.bin: for each frame f in [F0,F1): W*H*4 f32, row 0 = bottom row (GL).
@@ -25,7 +25,10 @@
  * shader drawn over a quad into an RGBA32F framebuffer texture with "frames" =
  * frames accumulated so far, alpha blending on, then glCopyTexSubImage2D into
  * the previous-frame texture), and ACC.bin receives the framebuffer texture
- * after every frame, same layout as OUT.bin.
+ * after every frame, same layout as OUT.bin.  --recreate-at F: before frame F
+ * the three textures are deleted and created again at the same size and the
+ * framebuffer re-attached, as Renderer.update_size does (renderer.py:347-382);
+ * the count of accumulated frames goes on, as the reference's does.
  * stdout: one JSON line with per-frame milliseconds (glFinish-bounded).
  */
 #define _GNU_SOURCE
@@ -82,7 +85,7 @@ int main(int argc, char **argv) {
     const char *shader = NULL, *uni = NULL, *out = NULL;
     const char *screen_vs = NULL, *screen_fs = NULL, *acc_out = NULL;
     const char *buf_path[16] = {0};
-    int W = 640, H = 360, f0 = 0, f1 = 1, reps = 1;
+    int W = 640, H = 360, f0 = 0, f1 = 1, reps = 1, recreate_at = -1;
     float bounces = 2.0f;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--shader")) shader = argv[++i];
@@ -96,6 +99,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--screen-vs")) screen_vs = argv[++i];
         else if (!strcmp(argv[i], "--screen-fs")) screen_fs = argv[++i];
         else if (!strcmp(argv[i], "--acc-out")) acc_out = argv[++i];
+        else if (!strcmp(argv[i], "--recreate-at")) recreate_at = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--spheres")) buf_path[5] = argv[++i];
         else if (!strcmp(argv[i], "--planes")) buf_path[6] = argv[++i];
         else if (!strcmp(argv[i], "--boxes")) buf_path[7] = argv[++i];
@@ -161,6 +165,7 @@ int main(int argc, char **argv) {
     GLF(PFNGLGETPROGRAMINFOLOGPROC, glGetProgramInfoLog);
     GLF(PFNGLUSEPROGRAMPROC, glUseProgram);
     GLF(PFNGLGENTEXTURESPROC, glGenTextures);
+    GLF(PFNGLDELETETEXTURESPROC, glDeleteTextures);
     GLF(PFNGLBINDTEXTUREPROC, glBindTexture);
     GLF(PFNGLTEXSTORAGE2DPROC, glTexStorage2D);
     GLF(PFNGLBINDIMAGETEXTUREPROC, glBindImageTexture);
@@ -317,6 +322,30 @@ int main(int argc, char **argv) {
     int first = 1;
     for (int f = f0; f < f1; f++) {
         double best = 1e300;
+        if (accumulate && f == recreate_at) {
+            glDeleteTextures(3, tex3);
+            glGenTextures(3, tex3);
+            const GLenum unit[3] = {GL_TEXTURE0, GL_TEXTURE1, GL_TEXTURE0}; /* renderer.py:367-369 */
+            for (int i = 0; i < 3; i++) {
+                glActiveTexture(unit[i]);
+                glBindTexture(GL_TEXTURE_2D, tex3[i]);
+                glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
+                glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
+                glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+                glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+                glTexStorage2D(GL_TEXTURE_2D, 1, GL_RGBA32F, W, H);
+            }
+            tex = tex3[0];
+            glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+            glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, tex3[2], 0);
+            if (glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) die("framebuffer incomplete");
+            glBindFramebuffer(GL_FRAMEBUFFER, 0);
+            /* the next render() binds the compute image again (renderer.py:176-180); unit 1 keeps the
+               new previous-frame texture bound above */
+            glActiveTexture(GL_TEXTURE0);
+            glBindTexture(GL_TEXTURE_2D, tex);
+            glBindImageTexture(0, tex, 0, GL_FALSE, 0, GL_READ_WRITE, GL_RGBA32F);
+        }
         for (int r = 0; r < reps; r++) {
             const float zero[4] = {0, 0, 0, 0};
             glClearTexImage(tex, 0, GL_RGBA, GL_FLOAT, zero);

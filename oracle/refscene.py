@@ -95,6 +95,9 @@ def build_reference_scene(scene: dict, mesh_tris: list[tuple[np.ndarray, int]] |
             )
             mats.append(mo.ogl_ssbo_data)
         mats_b = np.concatenate(mats).tobytes()
+        # the arrays exactly as the reference loader hands them to Renderer.update_ssbo
+        # (structured dtypes; shape (n,) for materials, (n, 1) for spheres and triangles)
+        args = {"materials": np.concatenate(mats)}  # scene.py:91-97 concatenates pairwise: same array
         prims = []
         # spheres: scene.py:100-122
         sph = []
@@ -107,6 +110,8 @@ def build_reference_scene(scene: dict, mesh_tris: list[tuple[np.ndarray, int]] |
             sph.append(sp.ogl_ssbo_data)
             prims.append({"primitive": sp, "index": index, "primitive_type": "sphere"})
         sph_b = np.concatenate(sph).tobytes() if sph else b""
+        if sph:
+            args["spheres"] = np.concatenate([sph])  # scene.py:121
         # quads: scene.py:196-248
         tri_data = []
         max_index = 0
@@ -129,6 +134,8 @@ def build_reference_scene(scene: dict, mesh_tris: list[tuple[np.ndarray, int]] |
                 prims.append({"primitive": tr, "index": j + max_index, "primitive_type": "triangle"})
                 tri_data.append(tr.ogl_ssbo_data)
         tris_b = np.vstack(tri_data).tobytes() if tri_data else b""
+        if tri_data:
+            args["triangles"] = np.vstack(tri_data)  # scene.py:191
         # boxes: what scene.py:125-147 intends (the call at :31 is commented out and the function
         # appends the growing list instead of the primitive; the primitive itself is used here)
         box_data = []
@@ -146,6 +153,9 @@ def build_reference_scene(scene: dict, mesh_tris: list[tuple[np.ndarray, int]] |
         q = QBVHNode.from_bvh(root)
         q.flatten_qbvh()
         bvh_b = q.ogl_ssbo_data.tobytes()
+        args["bvh"] = q.ogl_ssbo_data  # scene.py:62
+        args["scene_min_coords"] = root.aabb.min  # scene.py:70-71
+        args["scene_extent"] = root.aabb.max - root.aabb.min
         smin = np.asarray(root.aabb.min, dtype=np.float32)
         sext = np.asarray(root.aabb.max - root.aabb.min, dtype=np.float32)
     return {
@@ -157,6 +167,7 @@ def build_reference_scene(scene: dict, mesh_tris: list[tuple[np.ndarray, int]] |
         "planes": planes_b,
         "scene_min": smin,
         "scene_extent": sext,
+        "update_ssbo_args": args,
     }
 
 

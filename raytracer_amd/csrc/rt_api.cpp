@@ -116,7 +116,6 @@ struct rt_ctx {
     // fast mode (opt-in; rt_set_fast_mode): the library's own tree, built on the host from copies
     // of the uploaded triangles, spheres and boxes
     bool fast = false, fast_dirty = true;
-    std::vector<uint32_t> host_tris, host_spheres, host_boxes;
     rt::FastBvh fbvh;
     float4 *fnodes = nullptr;
     size_t fnodes_cap = 0;  // bytes
@@ -231,7 +230,7 @@ int alloc_images(rt_ctx *c, int width, int height) {
     }
     c->W = width;
     c->H = height;
-    c->rendered_frames = 0;
+    // rendered_frames stays: the reference's update_size leaves its counter alone (renderer.py:347-382)
     c->main_dirty = true;
     c->sum2_dirty = false;
     c->acc_recorded[0] = c->acc_recorded[1] = false;
@@ -349,9 +348,14 @@ int prepare_fast(rt_ctx *c) {
     if (!c->fast_dirty) return 0;
     if (int rc = sync_all(c)) return rc;  // frames in flight still read the old tree
     c->main_dirty = true;
-    rt::build_fast_bvh(c->host_tris.data(), (uint32_t)(c->host_tris.size() / 16), c->host_spheres.data(),
-                       (uint32_t)(c->host_spheres.size() / 8), c->host_boxes.data(), (uint32_t)(c->host_boxes.size() / 8),
-                       c->fbvh);
+    // the primitives as uploaded, read back from the device (only a context that enables fast mode pays for this)
+    std::vector<uint32_t> tris(c->tris.raw_bytes / 4), spheres(c->spheres.raw_bytes / 4), boxes(c->boxes.raw_bytes / 4);
+    if (!tris.empty()) HIP_TRY(hipMemcpy(tris.data(), c->tris.raw, c->tris.raw_bytes, hipMemcpyDeviceToHost));
+    if (!spheres.empty()) HIP_TRY(hipMemcpy(spheres.data(), c->spheres.raw, c->spheres.raw_bytes, hipMemcpyDeviceToHost));
+    if (!boxes.empty()) HIP_TRY(hipMemcpy(boxes.data(), c->boxes.raw, c->boxes.raw_bytes, hipMemcpyDeviceToHost));
+    if (rt::build_fast_bvh(tris.data(), (uint32_t)(tris.size() / 16), spheres.data(), (uint32_t)(spheres.size() / 8),
+                                    boxes.data(), (uint32_t)(boxes.size() / 8), c->fbvh))
+        return fail("rt_set_fast_mode: the scene's coordinates are too large for the fast-mode tree's quantised boxes");
     const size_t nb = c->fbvh.nodes.size() * 4;
     if (nb > c->fnodes_cap) {
         if (c->fnodes) HIP_TRY(hipFree(c->fnodes));
@@ -691,12 +695,12 @@ int rt_upload(rt_ctx *c, int binding, const void *data, size_t nbytes) {
     b->count = 0;
     b->dirty = true;
     if (binding != RT_BINDING_MATERIALS) c->tuned = false, c->plain_frames = 0;  // a new scene: time the variants again
-    std::vector<uint32_t> *mirror = binding == RT_BINDING_BVH         ? &c->host_nodes
-                                    : binding == RT_BINDING_TRIANGLES ? &c->host_tris
-                                    : binding == RT_BINDING_SPHERES   ? &c->host_spheres
-                                    : binding == RT_BINDING_BOXES     ? &c->host_boxes : nullptr;
+    // host copy of the node words (the breadth-first renumbering walks them); the fast-mode tree reads
+    // the primitives back from the device when it is first needed (prepare_fast)
+    std::vector<uint32_t> *mirror = binding == RT_BINDING_BVH ? &c->host_nodes : nullptr;
     if (mirror) mirror->clear();
-    if (mirror && binding != RT_BINDING_BVH) c->fast_dirty = true;
+    if (binding == RT_BINDING_TRIANGLES || binding == RT_BINDING_SPHERES || binding == RT_BINDING_BOXES)
+        c->fast_dirty = true;
     if (old_raw) HIP_TRY(hipFree(old_raw));
     if (nbytes) {
         uint32_t *raw = nullptr;
@@ -793,6 +797,12 @@ int rt_reset_accumulation(rt_ctx *c) {
     HIP_TRY(hipEventRecord(c->ev_acc[c->last_sample], c->stream));
     c->acc_recorded[c->last_sample] = true;
     c->rendered_frames = 0;
+    return 0;
+}
+
+int rt_set_rendered_frames(rt_ctx *c, uint32_t frames) {
+    if (!c) return fail("rt_set_rendered_frames: null context");
+    c->rendered_frames = frames;  // read on the host when a frame is queued: frames already queued keep theirs
     return 0;
 }
 
@@ -982,6 +992,40 @@ int rt_traversal_variant(rt_ctx *c, int *leaf_steps, int *decided) {
     if (!c || !leaf_steps || !decided) return fail("rt_traversal_variant: null argument");
     *leaf_steps = c->leaf_steps;
     *decided = (c->tune_fixed || c->tuned) ? 1 : 0;
+    return 0;
+}
+
+int rt_set_traversal_variant(rt_ctx *c, int variant) {
+    if (!c) return fail("rt_set_traversal_variant: null context");
+    if (variant < -1 || variant > 1) return fail("rt_set_traversal_variant: variant must be -1, 0 or 1");
+    if (variant < 0) {
+        c->tune_fixed = false;
+        c->tuned = false, c->tuned_records = 0, c->plain_frames = 0;
+    } else {
+        c->leaf_steps = variant;
+        c->tune_fixed = true;
+    }
+    return 0;
+}
+
+int rt_device_info(rt_ctx *c, int *device, char *pci_bus_id, size_t pci_bus_id_bytes) {
+    if (!c || !device || !pci_bus_id) return fail("rt_device_info: null argument");
+    if (pci_bus_id_bytes < 16) return fail("rt_device_info: pci_bus_id must hold at least 16 bytes");
+    *device = c->device;
+    HIP_TRY(hipDeviceGetPCIBusId(pci_bus_id, (int)pci_bus_id_bytes, c->device));
+    return 0;
+}
+
+int rt_shader_clock(rt_ctx *c, double *ghz) {
+    if (!c || !ghz) return fail("rt_shader_clock: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    rt::Counters hs[rt::kCounterStripes];
+    if (int rc = join(c)) return rc;
+    HIP_TRY(hipMemcpyAsync(hs, c->counters, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned long long cycles = 0, ticks = 0;
+    for (const rt::Counters &h : hs) cycles += h.clk_cycles, ticks += h.clk_ticks;
+    *ghz = ticks ? (double)cycles / (double)ticks * 0.1 : 0.0;  // ticks of the constant 100 MHz counter
     return 0;
 }
 

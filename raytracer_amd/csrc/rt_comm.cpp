@@ -26,6 +26,8 @@ struct Rccl {
     ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
 };
 
 std::mutex g_mu;
@@ -54,6 +56,8 @@ int load_rccl() {
     SYM(Reduce, "ncclReduce");
     SYM(AllReduce, "ncclAllReduce");
     SYM(GetErrorString, "ncclGetErrorString");
+    SYM(CommCount, "ncclCommCount");
+    SYM(CommUserRank, "ncclCommUserRank");
 #undef SYM
     g_rccl = r;
     return 0;
@@ -137,6 +141,15 @@ int rt_comm_all_reduce_f64(rt_ctx *ctx, double *values, int count, int op) {
     NCCL_TRY(g_rccl.AllReduce(dev, dev, (size_t)count, ncclFloat64, op == RT_COMM_SUM ? ncclSum : ncclMax, comm, s));
     HIP_TRY(hipMemcpyAsync(values, dev, sizeof(double) * count, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int rt_comm_info(rt_ctx *ctx, int *rank, int *nranks) {
+    if (!ctx || !rank || !nranks) return fail("rt_comm_info: null argument");
+    ncclComm_t comm = static_cast<ncclComm_t>(rt::ctx_comm(ctx));
+    if (!comm) return fail("rt_comm_info: rt_comm_init has not been called on this context");
+    NCCL_TRY(g_rccl.CommUserRank(comm, rank));
+    NCCL_TRY(g_rccl.CommCount(comm, nranks));
     return 0;
 }
 

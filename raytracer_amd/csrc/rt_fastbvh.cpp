@@ -87,7 +87,11 @@ struct Builder {
     std::vector<Prim> prims;
     std::vector<BinNode> nodes;
 
-    uint32_t build(uint32_t first, uint32_t count) {
+    // Recursion depth: a SAH split may peel off one primitive at a time (geometrically spaced
+    // centroids), which would make the depth grow with the primitive count; past kMaxSahDepth the
+    // split is the median of the widest centroid axis, so the depth stays below kMaxSahDepth + log2(n).
+    static constexpr int kMaxSahDepth = 48;
+    uint32_t build(uint32_t first, uint32_t count, int depth = 0) {
         const uint32_t me = (uint32_t)nodes.size();
         nodes.emplace_back();
         Box3 box, cbox;
@@ -108,9 +112,9 @@ struct Builder {
         // best binned split over the three axes
         float best_cost = std::numeric_limits<float>::infinity();
         int best_axis = -1, best_bin = 0;
-        for (int a = 0; a < 3; a++) {
+        for (int a = 0; a < 3 && depth < kMaxSahDepth; a++) {
             const float ext = cbox.hi[a] - cbox.lo[a];
-            if (!(ext > 0.0f)) continue;
+            if (!(ext > 0.0f) || !std::isfinite(ext)) continue;
             Box3 bb[kBins];
             uint32_t bn[kBins] = {0};
             for (auto &b : bb) b.reset();
@@ -157,11 +161,17 @@ struct Builder {
             });
             mid = (uint32_t)(it - prims.begin());
         } else {
-            mid = first + count / 2;  // all centroids coincide: any split will do
+            // no SAH split (all centroids coincide, or the depth limit): the median of the widest axis
+            int a = 0;
+            for (int k = 1; k < 3; k++)
+                if (cbox.hi[k] - cbox.lo[k] > cbox.hi[a] - cbox.lo[a]) a = k;
+            mid = first + count / 2;
+            std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+                             [a](const Prim &x, const Prim &y) { return x.c[a] < y.c[a]; });
         }
         if (mid == first || mid == first + count) mid = first + count / 2;
-        const uint32_t l = build(first, mid - first);
-        const uint32_t r = build(mid, first + count - mid);
+        const uint32_t l = build(first, mid - first, depth + 1);
+        const uint32_t r = build(mid, first + count - mid, depth + 1);
         nodes[me].left = l, nodes[me].right = r;
         return me;
     }
@@ -169,9 +179,12 @@ struct Builder {
 
 // Smallest biased exponent e (scale = 2^(e-127)) and codes such that every child plane decodes
 // outward of the exact one: lo' = fma(qlo, scale, origin) <= lo, hi' = fma(qhi, scale, origin) >= hi.
-void quantise_axis(float origin, float extent, const float *clo, const float *chi, int nchild, uint32_t &e_out,
+// Returns false if no exponent gives conservative codes (coordinates near the end of the float
+// range, where the extent overflows): such a scene cannot be held by this node format.
+bool quantise_axis(float origin, float extent, const float *clo, const float *chi, int nchild, uint32_t &e_out,
                    uint8_t *qlo, uint8_t *qhi) {
     int e = 1;
+    if (!std::isfinite(extent) || !std::isfinite(origin)) return false;
     if (extent > 0.0f) {
         int ex;
         std::frexp(extent / 255.0f, &ex);  // extent/255 = m * 2^ex, m in [0.5, 1)  ->  2^ex >= extent/255
@@ -190,15 +203,17 @@ void quantise_axis(float origin, float extent, const float *clo, const float *ch
             if (std::fma((float)lo, scale, origin) > clo[c] || std::fma((float)hi, scale, origin) < chi[c]) ok = false;
             qlo[c] = (uint8_t)lo, qhi[c] = (uint8_t)hi;
         }
-        if (ok || e >= 254) break;
+        if (ok) break;
+        if (e >= 254) return false;
     }
     e_out = (uint32_t)e;
+    return true;
 }
 
 }  // namespace
 
-void build_fast_bvh(const uint32_t *tris, uint32_t n_tris, const uint32_t *spheres, uint32_t n_spheres,
-                    const uint32_t *boxes, uint32_t n_boxes, FastBvh &out) {
+int build_fast_bvh(const uint32_t *tris, uint32_t n_tris, const uint32_t *spheres, uint32_t n_spheres,
+                   const uint32_t *boxes, uint32_t n_boxes, FastBvh &out) {
     Builder b;
     b.prims.reserve((size_t)n_tris + n_spheres + n_boxes);
     auto add = [&](Box3 box, uint32_t meta) {
@@ -252,7 +267,7 @@ void build_fast_bvh(const uint32_t *tris, uint32_t n_tris, const uint32_t *spher
         out.nodes.insert(out.nodes.end(), empty, empty + 16);
         out.nodes.insert(out.nodes.end(), empty, empty + 16);
         out.n_nodes = 1;
-        return;
+        return 0;
     }
     b.nodes.reserve((size_t)np * 2);
     const uint32_t root = b.build(0, np);
@@ -302,7 +317,10 @@ void build_fast_bvh(const uint32_t *tris, uint32_t n_tris, const uint32_t *spher
         uint32_t ex[3];
         for (int a = 0; a < 3; a++) {
             uint8_t qlo[4] = {0, 0, 0, 0}, qhi[4] = {0, 0, 0, 0};
-            quantise_axis(box.lo[a], box.hi[a] - box.lo[a], clo[a], chi[a], nk, ex[a], qlo, qhi);
+            if (!quantise_axis(box.lo[a], box.hi[a] - box.lo[a], clo[a], chi[a], nk, ex[a], qlo, qhi)) {
+                out = FastBvh();
+                return 1;
+            }
             w[a] = bits(box.lo[a]);
             w[4 + 2 * a] = qlo[0] | (qlo[1] << 8) | (qlo[2] << 16) | ((uint32_t)qlo[3] << 24);
             w[5 + 2 * a] = qhi[0] | (qhi[1] << 8) | (qhi[2] << 16) | ((uint32_t)qhi[3] << 24);
@@ -312,6 +330,7 @@ void build_fast_bvh(const uint32_t *tris, uint32_t n_tris, const uint32_t *spher
     }
     out.n_nodes = (uint32_t)(out.nodes.size() / 16);
     out.nodes.insert(out.nodes.end(), empty, empty + 16);  // the sentinel
+    return 0;
 }
 
 }  // namespace rt

@@ -54,7 +54,11 @@ constexpr int kCounterStripes = 64;
 struct Counters {  // 16 x u64 = one 128-byte line
     unsigned long long rays, pixel_samples, nodes, tri_tests, sphere_tests, box_tests, max_stack, stack_overflows;
     unsigned long long hits;
-    unsigned long long pad[7];
+    // Clock sample of the megakernel: a few of its wavefronts (one workgroup in 61) add the shader
+    // cycles they lived for (s_memtime) and the same span in ticks of the constant 100 MHz counter
+    // (s_memrealtime); cycles / ticks * 0.1 is the shader clock in GHz those wavefronts ran at.
+    unsigned long long clk_cycles, clk_ticks;
+    unsigned long long pad[5];
 };
 
 struct TraceParams {

@@ -1165,7 +1165,10 @@ __device__ __forceinline__ void trace_body(const TraceParams &p) {
     LdsTop top = (LdsTop)lds_top;
     int x, y;
     uint32_t macro;
-    const unsigned long long t_begin = p.cost ? __builtin_readcyclecounter() : 0ull;
+    // one workgroup in 61 samples the clock it runs at (Counters::clk_cycles / clk_ticks)
+    const bool clock_probe = (blockIdx.x % 61u) == 0u;
+    const unsigned long long t_begin = (p.cost || clock_probe) ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long r_begin = clock_probe ? __builtin_amdgcn_s_memrealtime() : 0ull;
     bool live = trace_pixel(p, true, x, y, macro);
     uint32_t lane = threadIdx.x & 63u;
     uint32_t *stack = lds_stack + threadIdx.x;
@@ -1211,6 +1214,11 @@ __device__ __forceinline__ void trace_body(const TraceParams &p) {
     flush_counters<STATS>(p.counters, lane, nrays, st);
     if (p.cost && lane == 0u && macro != 0xFFFFFFFFu)
         atomicAdd(&p.cost[macro], (uint32_t)((__builtin_readcyclecounter() - t_begin) >> 6));
+    if (clock_probe && threadIdx.x == 0u) {
+        Counters *c = p.counters + (blockIdx.x & (uint32_t)(kCounterStripes - 1));
+        atomicAdd(&c->clk_cycles, (unsigned long long)(__builtin_readcyclecounter() - t_begin));
+        atomicAdd(&c->clk_ticks, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r_begin));
+    }
 }
 
 // One workgroup per XCD: its macro tiles (indices x, x + 8, x + 16, ...) sorted by recorded cost,

@@ -287,7 +287,10 @@ int rts_build_fast_bvh(const uint32_t *tris, uint32_t n_tris, const uint32_t *sp
         return 1;
     }
     rt::FastBvh b;
-    rt::build_fast_bvh(tris, n_tris, spheres, n_spheres, boxes, n_boxes, b);
+    if (rt::build_fast_bvh(tris, n_tris, spheres, n_spheres, boxes, n_boxes, b)) {
+        g_err = "rts_build_fast_bvh: the scene's coordinates are too large for conservative 8-bit child boxes";
+        return 1;
+    }
     uint32_t *n = (uint32_t *)malloc(b.nodes.size() * 4);
     if (!n) {
         g_err = "rts_build_fast_bvh: out of memory";

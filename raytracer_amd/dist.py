@@ -79,13 +79,29 @@ def finalize_mean_srgb(sum_rgba: np.ndarray, spp: int) -> np.ndarray:
 # ------------------------------------------------------------------------------------------------
 # launching and rendezvous (host side only: nothing here touches a GPU)
 # ------------------------------------------------------------------------------------------------
+def _tail(path: Path, nbytes: int = 4000) -> str:
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, os.SEEK_END)
+            size = f.tell()
+            f.seek(max(0, size - nbytes))
+            return f.read().decode(errors="replace")
+    except OSError:
+        return ""
+
+
 def spawn_ranks(argv: list[str], world: int, extra_env: dict | None = None, timeout: float | None = None) -> int:
     """Starts `world` fresh processes running `argv`, one per GPU, with RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_ADDR / MASTER_PORT / RT_RDZV_DIR set, relays rank 0's stdout, and returns 0
-    only if every rank exited with 0.  The caller must not have initialised the GPU."""
-    rdzv = tempfile.mkdtemp(prefix="rt_mi355x_rdzv_")
-    procs = []
+    only if every rank exited with 0.  Every rank's stderr goes to a file of its own in the
+    rendezvous directory; rank 0's is relayed in full, and when ranks fail (or the run times out)
+    the tail of each failing rank's -- and of the ranks still waiting for it -- follows, so that a
+    failure on a machine nobody can log into leaves its reason in the launcher's output.  The caller
+    must not have initialised the GPU."""
+    rdzv = tempfile.mkdtemp(prefix="rt_mi355x_rdzv_")  # mode 0700, owned by this user
+    procs, errs = [], []
     out_path = Path(rdzv) / "rank0.stdout"
+    err_paths = [Path(rdzv) / f"rank{r}.stderr" for r in range(world)]
     try:
         with open(out_path, "wb") as out0:
             for rank in range(world):
@@ -95,7 +111,9 @@ def spawn_ranks(argv: list[str], world: int, extra_env: dict | None = None, time
                             "RT_RDZV_DIR": rdzv,
                             "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
                 env.update(extra_env or {})
-                procs.append(subprocess.Popen(argv, env=env, stdout=out0 if rank == 0 else subprocess.DEVNULL))
+                errs.append(open(err_paths[rank], "wb"))
+                procs.append(subprocess.Popen(argv, env=env, stdout=out0 if rank == 0 else subprocess.DEVNULL,
+                                              stderr=errs[-1]))
             # a rank that dies would leave the others waiting in a collective for ever: watch them all
             t0, failed = time.time(), []
             while True:
@@ -107,28 +125,52 @@ def spawn_ranks(argv: list[str], world: int, extra_env: dict | None = None, time
                     failed = [("timeout", timeout)]
                     break
                 time.sleep(0.02)
+        still_running = [r for r, p in enumerate(procs) if p.poll() is None]
+        for p in procs:
+            if p.poll() is None:
+                p.kill()  # exactly the processes started here
+                p.wait()
+        for e in errs:
+            e.close()
         sys.stdout.write(out_path.read_text(errors="replace"))
         sys.stdout.flush()
+        sys.stderr.write(err_paths[0].read_text(errors="replace"))
         if failed:
             print(f"spawn_ranks: ranks failed out of {world} (rank, exit code): {failed}", file=sys.stderr)
+            bad = [r for r, _ in failed if isinstance(r, int)]
+            for r in sorted(set(bad + still_running)):
+                if r == 0:
+                    continue  # relayed in full above
+                what = "failed" if r in bad else "was still running (killed)"
+                print(f"---- rank {r} {what}; tail of its stderr ----\n{_tail(err_paths[r])}", file=sys.stderr)
             return 1
         return 0
     finally:
         for p in procs:
             if p.poll() is None:
-                p.kill()  # exactly the processes started here
+                p.kill()
                 p.wait()
-        for f in Path(rdzv).glob("*"):
-            f.unlink()
-        for f in Path(rdzv).glob(".*"):
-            f.unlink()
-        os.rmdir(rdzv)
+        for e in errs:
+            if not e.closed:
+                e.close()
+        for f in list(Path(rdzv).glob("*")) + list(Path(rdzv).glob(".*")):
+            try:
+                f.unlink()
+            except OSError:
+                pass
+        try:
+            os.rmdir(rdzv)
+        except OSError:
+            pass
 
 
 def rendezvous_dir() -> Path:
-    """Directory shared by the ranks of this run: RT_RDZV_DIR when spawn_ranks launched them,
-    otherwise derived from what all ranks of one launcher have in common (the launcher's pid and
-    start time, and MASTER_PORT)."""
+    """Directory shared by the ranks of this run: RT_RDZV_DIR when spawn_ranks launched them (a
+    fresh mkdtemp directory), otherwise derived from what all ranks of one external launcher have in
+    common: the launcher's pid and start time, MASTER_PORT, and the launcher's run id / restart
+    count when it exports them (torch.distributed.run does), so that a restarted or later run never
+    reads an earlier run's blobs.  The directory is created with mode 0700 and must belong to this
+    user: another local user cannot plant an id in it."""
     d = os.environ.get("RT_RDZV_DIR")
     if d:
         return Path(d)
@@ -137,8 +179,19 @@ def rendezvous_dir() -> Path:
         start = Path(f"/proc/{ppid}/stat").read_text().rsplit(")", 1)[1].split()[19]
     except OSError:
         start = "0"
-    path = Path(tempfile.gettempdir()) / f"rt_mi355x_rdzv_{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}"
-    path.mkdir(exist_ok=True)
+    run = "_".join(os.environ.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"))
+    run = "".join(ch if ch.isalnum() or ch in "_-" else "-" for ch in run)[:64]
+    path = Path(tempfile.gettempdir()) / f"rt_mi355x_rdzv_{os.getuid()}_{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}_{run}"
+    try:
+        path.mkdir(mode=0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(path)
+    import stat as _stat
+
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError(f"rendezvous: {path} exists but is not a private directory of this user; "
+                           "set RT_RDZV_DIR to a directory only this run's ranks can write")
     return path
 
 
@@ -210,6 +263,24 @@ class Comm:
 
     def barrier(self) -> None:
         self.all_reduce([1.0])
+
+    def gather(self, values) -> np.ndarray:
+        """(world, k) array of every rank's k float64 values, on every rank (k * world <= 64)."""
+        v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        slots = np.zeros((self.world, v.size))
+        slots[self.rank] = v
+        return self.all_reduce(slots.reshape(-1), "sum").reshape(self.world, v.size)
+
+    def info(self) -> tuple[int, int]:
+        """(rank, number of ranks) as the communicator itself reports them: RCCL's own view when it
+        is in use, the constructor's arguments otherwise (one rank, or a rehearsal)."""
+        from . import _lib
+
+        if self.world == 1 or self.rehearse:
+            return self.rank, self.world
+        a, b = C.c_int(), C.c_int()
+        _lib.check(self._L.rt_comm_info(self.r._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def reduce_sum_image(self, root: int = 0) -> None:
         """Adds every rank's own linear sum image into rank `root`'s (one collective per run)."""

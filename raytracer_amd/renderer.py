@@ -98,10 +98,11 @@ class Renderer:
         _lib.check(self._L.rt_upload(self._ctx, int(index), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
 
     def update_size(self, width: int, height: int) -> None:
+        """reference renderer.py:347-382: the three images are recreated (black); `rendered_frames`
+        is left alone, so the next frame is blended into black with weight 1/(rendered_frames+1)."""
         self._width = is_positive_int(width)
         self._height = is_positive_int(height)
         _lib.check(self._L.rt_resize(self._ctx, self._width, self._height))
-        self.rendered_frames = 0
 
     def reset_accumulation(self) -> None:
         _lib.check(self._L.rt_reset_accumulation(self._ctx))
@@ -116,6 +117,9 @@ class Renderer:
             self._camera.changed = False
             self.reset_accumulation()
         self._push_uniforms()
+        # `rendered_frames` is a plain attribute in the reference and goes into the accumulate pass as
+        # it stands (renderer.py:255-257): whatever the host assigned is what the library starts from
+        _lib.check(self._L.rt_set_rendered_frames(self._ctx, is_positive_int(self.rendered_frames)))
         _lib.check(self._L.rt_render(self._ctx, self._frames, int(frames), float(self._bounces), self._flags))
         self._frames += int(frames)
         self.rendered_frames += int(frames)
@@ -165,6 +169,27 @@ class Renderer:
         ls, dec = C.c_int(), C.c_int()
         _lib.check(self._L.rt_traversal_variant(self._ctx, C.byref(ls), C.byref(dec)))
         return ("leaf steps" if ls.value else "unified"), bool(dec.value)
+
+    def set_traversal_variant(self, variant: str | None) -> None:
+        """Fixes the traversal variant ("unified" or "leaf steps") for this renderer, which also keeps
+        the library from timing the two with four extra launches at the 65th frame of a scene; None
+        returns to the automatic choice."""
+        v = {None: -1, "unified": 0, "leaf steps": 1}[variant]
+        _lib.check(self._L.rt_set_traversal_variant(self._ctx, v))
+
+    def device_info(self) -> tuple[int, str]:
+        """(HIP device ordinal, PCI bus id) of the GPU this renderer runs on."""
+        dev = C.c_int()
+        buf = C.create_string_buffer(32)
+        _lib.check(self._L.rt_device_info(self._ctx, C.byref(dev), buf, 32))
+        return dev.value, buf.value.decode()
+
+    def shader_clock_ghz(self) -> float:
+        """Shader clock the trace kernel's wavefronts ran at since the last reset_stats(), as the
+        kernel measured it (0.0 if no launch sampled it)."""
+        g = C.c_double()
+        _lib.check(self._L.rt_shader_clock(self._ctx, C.byref(g)))
+        return g.value
 
     def fast_bvh(self) -> np.ndarray:
         """The fast-mode tree as built for the current scene: (n + 1, 16) uint32, the last node a sentinel."""

@@ -80,3 +80,32 @@ def test_rank_processes_render_shards_on_the_gpu_and_combine(tmp_path, world, mo
     else:                 # samples are added in another order: fp32 reassociation only
         np.testing.assert_allclose(got["sum"], want_sum, rtol=2e-6, atol=1e-6)
         assert np.abs(got["mean"] - want_mean).max() <= 1e-5
+
+
+def test_bench_rehearsal_with_eight_ranks_carries_the_diagnostics():
+    """bench.py --gpus 8 end to end, its own launcher included, with the eight ranks sharing this one
+    GPU (RT_BENCH_REHEARSE=1: collectives through host files, RCCL refuses several ranks on one
+    device; small image and scene): the line carries what a first run on eight GPUs must show --
+    the communicator's rank count, every rank's device and PCI bus id, the reduce time and its
+    warm-up, stack overflows, the sustained leg with the measured shader clock."""
+    import json
+    import os
+
+    env = dict(os.environ, RT_BENCH_REHEARSE="1")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--width", "320", "--height", "184", "--detail", "0.05", "--sustain-seconds", "0.2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["scaling"] == "weak"
+    assert "REHEARSAL" in out["data"]
+    assert len(out["ranks"]) == 8 and [r["rank"] for r in out["ranks"]] == list(range(8))
+    assert all(r["device"] == 0 and r["pci_bus_id"] != "unknown" for r in out["ranks"])
+    assert all(1.0 < r["shader_clock_GHz"] < 3.0 for r in out["ranks"]), out["ranks"]
+    assert out["stack_overflows"] == 0 and out["reduce_ms"] >= 0.0 and len(out["reduce_warmup_ms"]) == 2
+    assert out["sustained"]["frames"] >= 8 * 3 and out["sustained"]["value"] > 0
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    # weak scaling: every rank rendered its own frames of the same image
+    assert abs(out["config"]["rays_per_frame"] * 8 * 3 / (out["value"] * 1e6 * out["ms_per_step"] * 3e-3) - 1) < 0.05

@@ -191,6 +191,7 @@ def test_accumulation_matches_oracle(renderer):
     load_golden_scene(renderer, "gally")
     w, h, b = 320, 180, 4
     renderer.update_size(w, h)
+    renderer.rendered_frames = 0   # update_size leaves the count alone, as the reference's does
     sc = O.OracleScene.from_dir(GOLDEN / "gally")
     acc = np.zeros((h, w, 4), np.float32)
     for k in range(6):
@@ -215,6 +216,8 @@ def test_accumulation_matches_reference_fragment_shader(renderer, scene, tag):
     renderer.update_size(w, h)
     renderer.reset_accumulation()
     for f in range(*rec["frames"]):
+        if f == rec.get("update_size_before_frame"):
+            renderer.update_size(w, h)   # same size: the reference recreates its textures all the same
         render_frame(renderer, w, h, f, b)
         assert sha(renderer.read_sample()) == rec["sample_sha256_per_frame"][f]
         assert sha(renderer.read_accumulation()) == rec["acc_sha256_per_frame"][f], f"accumulation after frame {f}"
@@ -303,6 +306,29 @@ def test_random_scenes_match_reference_shader(renderer):
             img = render_frame(renderer, rec["w"], rec["h"], f, rec["bounces"])
             assert sha(img) == acc_rec["sample_sha256_per_frame"][f], (name, f)
             assert sha(renderer.read_accumulation()) == acc_rec["acc_sha256_per_frame"][f], (name, f)
+
+
+def test_the_reference_loaders_own_update_ssbo_arguments(renderer):
+    """The arrays exactly as the reference's load_scene hands them to Renderer.update_ssbo
+    (scene.py:62,97,121-122,191-193): structured dtypes, materials of shape (n,), spheres and
+    triangles of shape (n, 1), and numpy arrays for scene_min_coords / scene_extent -- fed
+    unchanged, in the loader's order, and rendered against the reference shader's images."""
+    args = np.load(GOLDEN / "debug" / "update_ssbo_args.npz")
+    assert args["spheres"].ndim == 2 and args["triangles"].ndim == 2 and args["materials"].dtype.names
+    renderer.update_ssbo(renderer.materials, args["materials"], 9)
+    renderer.update_ssbo(renderer.spheres, args["spheres"], 5)
+    renderer.update_ssbo(renderer.triangles, args["triangles"], 12)
+    renderer.update_ssbo(renderer.bvh, args["bvh"], 11)
+    for binding in (6, 7):
+        renderer.update_ssbo(0, np.zeros(0, np.uint8), binding)   # an earlier test's boxes and planes
+    renderer.scene_min_coords = args["scene_min_coords"]
+    renderer.scene_extent = args["scene_extent"]
+    u = np.fromfile(GOLDEN / "debug" / "uniforms.bin", dtype=np.float32)
+    renderer.set_uniforms(u[0:16], u[16:19])
+    rec = json.loads((GOLDEN / "debug" / "c1_640x360_b2.json").read_text())
+    for i, f in enumerate(range(*rec["frames"])):
+        img = render_frame(renderer, rec["w"], rec["h"], f, rec["bounces"])
+        assert sha(img) == rec["kinds"]["color"]["sha256_per_frame"][i], f
 
 
 def test_edge_sizes_and_truncated_dispatch(renderer):
@@ -451,8 +477,12 @@ def test_sum_mode_two_frames_in_flight_is_deterministic(renderer):
 
 def test_interactive_hooks_reset_the_running_mean(renderer):
     """The app loop's hooks (controller.py:124-128,218-219, window.py:199, renderer.py:170-173): a
-    camera change, a bounce-count change followed by reset_accumulation, and a resize all restart
-    the running mean; the frame counter that feeds `time` keeps counting."""
+    camera change and a bounce-count change followed by reset_accumulation restart the running mean;
+    a resize recreates the images but leaves `rendered_frames` alone (renderer.py:347-382), so the
+    next frame is blended into black with weight 1/(rendered_frames+1) -- pinned against the
+    reference's own shaders in test_accumulation_matches_reference_fragment_shader (resize_*); a
+    host that assigns `rendered_frames` itself is obeyed; the frame counter that feeds `time`
+    keeps counting."""
     load_golden_scene(renderer, "debug")
     w, h = 160, 88
     renderer.update_size(w, h)
@@ -483,14 +513,22 @@ def test_interactive_hooks_reset_the_running_mean(renderer):
     s5 = sc.render(w, h, 5, 3)
     assert np.array_equal(renderer.read_sample(), s5)
     assert np.array_equal(renderer.read_accumulation(), O.accumulate(s5, sc.render(w, h, 4, 2), 0))
-    # resize: fresh (zero) images
+    # resize: fresh (zero) images, the count of accumulated frames stays
     renderer.render()
+    assert renderer.rendered_frames == 2
     renderer.update_size(w + 16, h + 8)
-    assert renderer.rendered_frames == 0 and (renderer.width, renderer.height) == (w + 16, h + 8)
+    assert renderer.rendered_frames == 2 and (renderer.width, renderer.height) == (w + 16, h + 8)
     renderer.render()
     s7 = sc.render(w + 16, h + 8, 7, 3)
     assert np.array_equal(renderer.read_sample(), s7)
-    assert np.array_equal(renderer.read_accumulation(), O.accumulate(s7, np.zeros_like(s7), 0))
+    assert np.array_equal(renderer.read_accumulation(), O.accumulate(s7, np.zeros_like(s7), 2))
+    assert renderer.rendered_frames == 3
+    # the attribute is the host's to assign (renderer.py:106,255-257): a clean start after a resize
+    renderer.update_size(w, h)
+    renderer.rendered_frames = 0
+    renderer.render()
+    s8 = sc.render(w, h, 8, 3)
+    assert np.array_equal(renderer.read_accumulation(), O.accumulate(s8, np.zeros_like(s8), 0))
     with pytest.raises(TypeError):
         renderer.bounces = -1
 
@@ -704,5 +742,35 @@ def test_traversal_variant_is_timed_once_a_scene_is_in_use_and_changes_no_pixel(
         assert r.traversal_variant() == (name, True)
         r.update_size(w * 2, h * 2)  # a much larger image starts over
         assert r.traversal_variant()[1] is False
+    finally:
+        r.close()
+
+
+def test_traversal_variant_can_be_fixed_per_context():
+    """rt_set_traversal_variant: a host that must not see the one-off timing launches fixes the
+    variant itself; no frame count then triggers them, both variants render the reference shader's
+    images, and -1 hands the choice back to the library."""
+    from raytracer_amd.renderer import Renderer
+
+    scene, tag = _cases()[0]
+    rec = json.loads((GOLDEN / scene / f"{tag}.json").read_text())
+    hashes = rec["kinds"]["color"]["sha256_per_frame"] if "kinds" in rec else rec["sha256_per_frame"]
+    w, h, b = rec["w"], rec["h"], rec["bounces"]
+    f0 = rec["frames"][0]
+    r = Renderer(device=0, singleton=False)
+    try:
+        load_golden_scene(r, scene)
+        for name in ("unified", "leaf steps"):
+            r.set_traversal_variant(name)
+            assert r.traversal_variant() == (name, True)
+            for _ in range(70):   # beyond the 64 frames after which the library would time the variants
+                img = render_frame(r, w, h, f0, b)
+            assert sha(img) == hashes[0]
+            assert r.traversal_variant() == (name, True)
+        r.set_traversal_variant(None)
+        assert r.traversal_variant()[1] is False
+        with pytest.raises(RuntimeError, match="variant"):
+            from raytracer_amd import _lib
+            _lib.check(_lib.load().rt_set_traversal_variant(r._ctx, 2))
     finally:
         r.close()

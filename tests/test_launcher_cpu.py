@@ -68,6 +68,81 @@ def test_spawn_ranks_reports_a_failed_rank():
     assert "ranks failed" in p.stderr
 
 
+def test_spawn_ranks_relays_the_stderr_of_the_rank_that_failed():
+    code = ("import os, sys, time\n"
+            "rank = int(os.environ['RANK'])\n"
+            "print('diagnostic from rank', rank, file=sys.stderr, flush=True)\n"
+            "if rank == 2: raise SystemExit('rank two gives up: no such device')\n"
+            "time.sleep(30)\n")
+    launcher = ("import sys; sys.path.insert(0, %r); from raytracer_amd import dist as D; "
+                "sys.exit(D.spawn_ranks([sys.executable, '-c', %r], 4, timeout=60))" % (str(ROOT), code))
+    p = subprocess.run([sys.executable, "-c", launcher], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 1
+    assert "rank 2 failed" in p.stderr and "rank two gives up: no such device" in p.stderr
+    assert "diagnostic from rank 0" in p.stderr            # rank 0's stderr is always relayed
+    assert "rank 1 was still running" in p.stderr          # the ranks left waiting are named too
+
+
+def test_rendezvous_dir_of_an_external_launcher_is_private_and_per_run(tmp_path, monkeypatch):
+    sys.path.insert(0, str(ROOT))
+    from raytracer_amd import dist as D
+
+    monkeypatch.delenv("RT_RDZV_DIR", raising=False)
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    import tempfile
+
+    tempfile.tempdir = None   # re-read TMPDIR
+    try:
+        monkeypatch.setenv("MASTER_PORT", "29999")
+        monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+        monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+        a = D.rendezvous_dir()
+        assert a.parent == tmp_path and (os.stat(a).st_mode & 0o777) == 0o700
+        assert D.rendezvous_dir() == a                      # every rank of the run derives the same one
+        monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+        b = D.rendezvous_dir()
+        assert b != a                                       # a restarted run never reads the earlier run's blobs
+        os.chmod(b, 0o777)                                  # a directory others could have written is refused
+        try:
+            D.rendezvous_dir()
+            raise AssertionError("a world-writable rendezvous directory was accepted")
+        except RuntimeError as e:
+            assert "private" in str(e)
+    finally:
+        tempfile.tempdir = None
+
+
+def test_c4_line_carries_the_multi_gpu_diagnostics():
+    """The JSON line of an 8-rank run, assembled from stand-in measurements (the GPU rehearsal of the
+    same path is tests/test_gpu_multirank.py)."""
+    import argparse
+    import json
+
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    world = 8
+    args = argparse.Namespace(width=1920, height=1080, bounces=4, steps=20, warmup=3)
+    per = [[k, bench.pci_to_number("0000:%02x:00.0" % (5 + 16 * k)), 36.0 + k, 0.9, 2.1, 0, k] for k in range(world)]
+    m = {"elapsed": 0.040, "rays": 8.2e6 * 20 * world, "reduce_ms_max": 0.9, "reduce_warmup_ms": [55.0, 0.9],
+         "per_rank": per, "rccl_ranks": world, "ref_frame": None,
+         "sustained": {"value": 1.0, "ms_per_step": 1.8, "frames": 8 * 1100, "shader_clock_GHz": {}},
+         "fast": None, "kernel_ms": 1.94, "rays_per_launch": 8.2e6, "per_ray": (22.0, 3.7, 0.13, 0.99, 3.96),
+         "variant": "unified", "max_stack": 17, "build_s": 0.3}
+    out = json.loads(json.dumps(bench.assemble_c4(args, world, "sponza_synth(detail=1.0)", 265034, 132402, False, m)))
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["scaling"] == "weak"
+    assert abs(out["value"] - 8.2e6 * 20 * 8 / 0.040 / 1e6) < 1e-6
+    assert out["reduce_ms"] == 0.9 and out["reduce_warmup_ms"] == [55.0, 0.9] and out["stack_overflows"] == 0
+    assert [r["device"] for r in out["ranks"]] == list(range(8))
+    assert out["ranks"][3]["pci_bus_id"] == "0000:35:00.0" and out["ranks"][3]["comm_rank"] == 3
+    assert "sustained" in out and "fast_mode" not in out and out["reference_frame"] is None
+    assert "same step at every n_gpus" in out["config"]["step"]
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    for key in ("hbm_counter_frac", "td_busy", "vmem_frac", "l2_hit", "binding_resource"):
+        assert key in rf
+
+
 def test_bench_refuses_a_rank_count_that_does_not_match():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True,

@@ -141,6 +141,9 @@ def test_running_mean_bit_exact(scenes, scene, tag):
     if w > 1000:
         f1 = f0 + 3  # keep the CPU suite short; the GPU suite checks every frame
     for f in range(f0, f1):
+        if f == rec.get("update_size_before_frame"):
+            # Renderer.update_size (renderer.py:347-382): new, black textures; the frame count goes on
+            acc = np.zeros((h, w, 4), np.float32)
         s = sc.render(w, h, f, b)
         assert sha(s) == rec["sample_sha256_per_frame"][f]
         acc = O.accumulate(s, acc, f)

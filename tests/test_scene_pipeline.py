@@ -89,3 +89,16 @@ def test_variable_substitution_and_sphere_radius():
     b = S.build_scene(scene)
     assert b.spheres["radius"][0] == np.float32(0.4) and b.spheres["radius2"][0] == np.float32(0.4 * 0.4)
     assert b.spheres["radius"][1] == 1.0
+
+
+def test_reference_update_ssbo_arguments_are_the_golden_bytes():
+    """The structured arrays the reference loader passes to update_ssbo (captured with their dtypes
+    and shapes) hold exactly the bytes of the golden buffers, and numpy reports their size in bytes
+    the way Renderer.update_ssbo relies on."""
+    args = np.load(GOLDEN / "debug" / "update_ssbo_args.npz")
+    for key, name in (("materials", "mats.bin"), ("spheres", "spheres.bin"), ("triangles", "tris.bin"), ("bvh", "bvh.bin")):
+        a = np.ascontiguousarray(args[key])
+        assert a.tobytes() == (GOLDEN / "debug" / name).read_bytes(), key
+        assert a.nbytes == (GOLDEN / "debug" / name).stat().st_size
+    u = np.fromfile(GOLDEN / "debug" / "uniforms.bin", dtype=np.float32)
+    assert np.array_equal(args["scene_min_coords"], u[19:22]) and np.array_equal(args["scene_extent"], u[22:25])

@@ -89,8 +89,34 @@ static int run_case(uint32_t n, int kind, uint32_t seed) {
     return 0;
 }
 
+// Fast-mode builder only.  kind 0: centroids spaced geometrically along x (a SAH split peels off
+// one primitive at a time: the recursion depth must stay bounded); kind 1: coordinates at the end
+// of the float range (extents overflow: the builder must refuse the scene, not produce boxes that
+// are not conservative).
+static int run_fast_case(uint32_t n, int kind) {
+    std::vector<uint32_t> tris((size_t)n * 16, 0u);
+    for (uint32_t i = 0; i < n; i++) {
+        const float x = kind == 0 ? std::ldexp(1.0f, -100 + (int)(i % 200u)) * (1.0f + (float)(i / 200u) * 1e-4f)
+                                  : ((i & 1u) ? 3.0e38f : -3.0e38f);
+        const float v[3][3] = {{x, 0.f, 0.f}, {x * 1.0001f, 1.f, 0.f}, {x, 0.f, 1.f}};
+        for (int k = 0; k < 3; k++)
+            for (int a = 0; a < 3; a++) tris[(size_t)i * 16 + 4 * k + a] = f2u(v[k][a]);
+    }
+    uint32_t *fn = nullptr, fnn = 0;
+    const int rc = rts_build_fast_bvh(tris.data(), n, nullptr, 0, nullptr, 0, &fn, &fnn);
+    if (kind == 1) {
+        if (rc == 0) { printf("fast: a scene whose extents overflow was accepted\n"); rts_free(fn); return 1; }
+        return 0;
+    }
+    if (rc) { printf("fast skewed n=%u: %s\n", n, rts_last_error()); return 1; }
+    rts_free(fn);
+    return 0;
+}
+
 int main() {
     int bad = 0, cases = 0;
+    bad += run_fast_case(200000u, 0), cases++;
+    bad += run_fast_case(64u, 1), cases++;
     for (int kind = 0; kind < 4; kind++)
         for (uint32_t n : {0u, 1u, 2u, 3u, 4u, 5u, 17u, 64u, 1000u, 20000u}) {
             bad += run_case(n, kind, 1234u + n + 7u * (uint32_t)kind);
