@@ -486,6 +486,7 @@ def test_interactive_hooks_reset_the_running_mean(renderer):
     load_golden_scene(renderer, "debug")
     w, h = 160, 88
     renderer.update_size(w, h)
+    renderer.rendered_frames = 0   # the fixture's renderer has frames from earlier tests
     renderer.bounces = 2
     renderer.set_frame_index(0)
     renderer.camera.changed = False
