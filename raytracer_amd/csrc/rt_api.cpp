@@ -37,23 +37,75 @@ struct RawBuffer {           // device copy of an uploaded reference-layout buff
     bool dirty = true;        // packed is stale
 };
 
-// Breadth-first order of the node graph from node 0: order[new] = old, rank[old] = new.  Every
-// node appears exactly once (nodes the root does not reach keep their relative order at the end;
-// a child index is followed only the first time it is met, so malformed graphs are fine).
-void breadth_first_order(const uint32_t *nodes, uint32_t n, std::vector<uint32_t> &order, std::vector<uint32_t> &rank) {
+// Order of the device node records: order[new] = old, rank[old] = new.  Every node appears exactly
+// once (nodes the root does not reach keep their relative order at the end; a child index is followed
+// only the first time it is met, so malformed graphs are fine).
+// The first `top` records are always the breadth-first order from node 0: they are the ones a
+// workgroup copies into LDS.  Below them, `layout` chooses:
+//   0  breadth-first throughout;
+//   1  depth-first (pre-order) within the subtree of each node that did not make it into the top:
+//      a subtree's nodes are contiguous;
+//   2  treelets: the same, but the depth-first walk emits groups of up to 21 nodes (a node, its
+//      children, their children: three levels) before descending, so a ray's next few visits lie
+//      within a few KB (a van Emde Boas-like blocking).
+void node_order(const uint32_t *nodes, uint32_t n, uint32_t top, int layout, std::vector<uint32_t> &order,
+                std::vector<uint32_t> &rank) {
     order.clear();
     order.reserve(n);
     rank.assign(n, 0xFFFFFFFFu);
     if (n == 0) return;
-    rank[0] = 0;
-    order.push_back(0);
-    for (size_t head = 0; head < order.size(); head++) {
-        const uint32_t *meta = nodes + (size_t)order[head] * 16 + 12;
-        for (int k = 0; k < 4; k++) {
-            const uint32_t idx = meta[k] & 0x3FFFFFFFu;
-            if ((meta[k] >> 30) == 3u && idx < n && rank[idx] == 0xFFFFFFFFu) {
-                rank[idx] = (uint32_t)order.size();
-                order.push_back(idx);
+    auto children = [&](uint32_t node, uint32_t out[4]) {
+        int k = 0;
+        const uint32_t *meta = nodes + (size_t)node * 16 + 12;
+        for (int c = 0; c < 4; c++) {
+            const uint32_t idx = meta[c] & 0x3FFFFFFFu;
+            if ((meta[c] >> 30) == 3u && idx < n && rank[idx] == 0xFFFFFFFFu) out[k++] = idx;
+        }
+        return k;
+    };
+    auto emit = [&](uint32_t node) {
+        rank[node] = (uint32_t)order.size();
+        order.push_back(node);
+    };
+    emit(0);
+    const size_t bfs_limit = layout == 0 ? (size_t)n : (size_t)top;
+    size_t head = 0;
+    for (; head < order.size() && order.size() < bfs_limit; head++) {
+        uint32_t kids[4];
+        const int k = children(order[head], kids);
+        for (int c = 0; c < k; c++)
+            if (rank[kids[c]] == 0xFFFFFFFFu) emit(kids[c]);  // a child met twice within one node counts once
+    }
+    if (layout != 0) {
+        // the frontier: emitted nodes whose children have not been looked at yet, in breadth-first order
+        std::vector<uint32_t> stack;
+        for (size_t i = order.size(); i-- > head;) stack.push_back(order[i]);  // popped in breadth-first order
+        // every frontier node is already placed; what follows places its descendants
+        std::vector<uint32_t> level, next;
+        while (!stack.empty()) {
+            const uint32_t node = stack.back();
+            stack.pop_back();
+            if (layout == 1) {
+                uint32_t kids[4];
+                const int k = children(node, kids);
+                for (int c = 0; c < k; c++)
+                    if (rank[kids[c]] == 0xFFFFFFFFu) emit(kids[c]);
+                // (children are contiguous right after... their own subtrees follow, first child first)
+                for (int c = k - 1; c >= 0; c--) stack.push_back(kids[c]);
+            } else {
+                // two more levels below `node` form one treelet; its deepest level becomes new roots
+                level.assign(1, node);
+                for (int depth = 0; depth < 2; depth++) {
+                    next.clear();
+                    for (uint32_t m : level) {
+                        uint32_t kids[4];
+                        const int k = children(m, kids);
+                        for (int c = 0; c < k; c++)
+                            if (rank[kids[c]] == 0xFFFFFFFFu) emit(kids[c]), next.push_back(kids[c]);
+                    }
+                    level.swap(next);
+                }
+                for (size_t i = level.size(); i-- > 0;) stack.push_back(level[i]);
             }
         }
     }
@@ -148,6 +200,7 @@ struct rt_ctx {
     hipEvent_t ev_busy[2] = {nullptr, nullptr};  // end of the last trace kernel queued on trace stream b
     bool busy_recorded[2] = {false, false};
     bool lpt = true;
+    int node_layout = 0;  // order of the node records below the LDS copy (node_order; RT_NODE_LAYOUT, an experiment knob)
     uint32_t *lpt_cost[2] = {nullptr, nullptr}, *lpt_order[2] = {nullptr, nullptr};
     float *pinned = nullptr;  // page-locked host image handed out by rt_map_image
     size_t pinned_bytes = 0;
@@ -314,7 +367,7 @@ int repack(rt_ctx *c, int binding) {
     switch (binding) {
         case RT_BINDING_BVH: {
             std::vector<uint32_t> order, rank;
-            breadth_first_order(c->host_nodes.data(), b->count, order, rank);
+            node_order(c->host_nodes.data(), b->count, rt::kLdsTopNodes, c->node_layout, order, rank);
             if ((size_t)b->count + 1 > c->node_perm_cap) {
                 uint32_t *old_order = c->node_order, *old_rank = c->node_rank;
                 c->node_order = c->node_rank = nullptr, c->node_perm_cap = 0;
@@ -583,6 +636,7 @@ static int create_impl(rt_ctx *c, int device) {
     HIP_TRY(hipMemsetAsync(c->tune_counters, 0, sizeof(rt::Counters) * rt::kCounterStripes, c->stream));
     if (const char *e = getenv("RT_OVERLAP")) c->overlap = atoi(e) != 0;
     if (const char *e = getenv("RT_LPT")) c->lpt = atoi(e) != 0;
+    if (const char *e = getenv("RT_NODE_LAYOUT")) c->node_layout = atoi(e);
     for (int b = 0; b < 2; b++) {
         HIP_TRY(hipMalloc((void **)&c->lpt_cost[b], 8u * rt::kLptPerXcd * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void **)&c->lpt_order[b], 8u * rt::kLptPerXcd * sizeof(uint32_t)));

@@ -14,10 +14,7 @@
 namespace rt {
 
 #define RT_BLOCK 256
-#ifndef RT_LDS_TOP
-#define RT_LDS_TOP 109     // number of leading (breadth-first) nodes kept in LDS per workgroup: four levels (85) plus what fits in the
-                           // 20 KB a workgroup may use while 8 of them share a CU; 0 = none
-#endif
+// RT_LDS_TOP (rt_internal.h): number of leading (breadth-first) nodes kept in LDS per workgroup
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 4   // megakernel: wavefronts per workgroup, each an 8x8 quarter of a 16x16 tile (the regrouping kernel assumes 4)
 #endif

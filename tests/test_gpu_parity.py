@@ -775,3 +775,31 @@ def test_traversal_variant_can_be_fixed_per_context():
             _lib.check(_lib.load().rt_set_traversal_variant(r._ctx, 2))
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("layout", [1, 2])
+def test_node_record_layouts_change_no_pixel(layout):
+    """RT_NODE_LAYOUT (depth-first subtrees / three-level treelets below the LDS copy instead of
+    breadth-first order) renumbers the device node records only: images and first hits stay the
+    reference shader's."""
+    import os
+
+    from raytracer_amd.renderer import Renderer
+
+    os.environ["RT_NODE_LAYOUT"] = str(layout)
+    try:
+        r = Renderer(device=0, singleton=False)
+    finally:
+        os.environ.pop("RT_NODE_LAYOUT", None)
+    try:
+        for scene, tag in (("gally", "small_160x88_b4"), ("matlab", "small_160x88_b6")):
+            rec = json.loads((GOLDEN / scene / f"{tag}.json").read_text())
+            load_golden_scene(r, scene)
+            f0 = rec["frames"][0]
+            img = render_frame(r, rec["w"], rec["h"], f0, rec["bounces"], aux=True)
+            assert sha(img) == rec["kinds"]["color"]["sha256_per_frame"][0]
+            code, tbits, exists = O.primary_from_golden(np.load(GOLDEN / scene / f"{tag}.primary.npy")[0])
+            aux = r.read_aux()
+            assert np.array_equal(code, aux[..., 0]) and np.array_equal(tbits, aux[..., 1])
+    finally:
+        r.close()

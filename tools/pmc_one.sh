@@ -6,5 +6,5 @@ REPO=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export RT_OVERLAP=0
-timeout -s KILL 150 rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/$NAME" --output-format csv -- python3 "$REPO/bench.py" --no-cpu-baseline --steps 6 --warmup 1 > "$OUT/$NAME.log" 2>&1
+timeout -s KILL 150 rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/$NAME" --output-format csv -- python3 "$REPO/bench.py" --no-cpu-baseline --sustain-seconds 0 --steps 6 --warmup 1 > "$OUT/$NAME.log" 2>&1
 python3 "$REPO/tools/pmc_summary.py" "$OUT/$NAME" "${RT_PMC_KERNEL:-trace_kernel<1, false, false, false>}"

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 export RT_OVERLAP=0
 run() {
   name=$1; shift
-  timeout -s KILL 150 rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/$name" --output-format csv -- python3 "$REPO/bench.py" --no-cpu-baseline --steps 6 --warmup 1 "${EXTRA[@]}" > "$OUT/$name.log" 2>&1
+  timeout -s KILL 150 rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/$name" --output-format csv -- python3 "$REPO/bench.py" --no-cpu-baseline --sustain-seconds 0 --steps 6 --warmup 1 "${EXTRA[@]}" > "$OUT/$name.log" 2>&1
   python3 "$REPO/tools/pmc_summary.py" "$OUT/$name" "trace_kernel<1, false, false, false>" > "$OUT/$name.txt"
   cat "$OUT/$name.txt"
 }

@@ -12,7 +12,7 @@ if [ -n "$RT_PMC_KERNELS" ]; then IFS=';' read -r -a KERNELS <<< "$RT_PMC_KERNEL
 else KERNELS=("trace_regroup_kernel<1, false, false>" "trace_kernel<1, false, false, false>" "trace_kernel<1, false, false, true>"); fi
 run() {
   name=$1; shift
-  timeout -s KILL 150 rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/$name" --output-format csv -- python3 "$REPO/bench.py" --no-cpu-baseline --steps 6 --warmup 1 > "$OUT/$name.log" 2>&1
+  timeout -s KILL 150 rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/$name" --output-format csv -- python3 "$REPO/bench.py" --no-cpu-baseline --sustain-seconds 0 --steps 6 --warmup 1 > "$OUT/$name.log" 2>&1
   for k in "${KERNELS[@]}"; do
     echo "== $name $k"; python3 "$REPO/tools/pmc_summary.py" "$OUT/$name" "$k"
   done

@@ -8,8 +8,8 @@ OUT=$(realpath -m "$1")
 REPO=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-RT_OVERLAP=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/serial" --output-format csv -- python3 "$REPO/bench.py" --no-cpu-baseline --steps 20 --warmup 3 > "$OUT/serial_bench.json" 2> "$OUT/serial.err"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/overlap" --output-format csv -- python3 "$REPO/bench.py" --no-cpu-baseline --steps 20 --warmup 3 > "$OUT/overlap_bench.json" 2> "$OUT/overlap.err"
+RT_OVERLAP=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/serial" --output-format csv -- python3 "$REPO/bench.py" --no-cpu-baseline --sustain-seconds 0 --steps 20 --warmup 3 > "$OUT/serial_bench.json" 2> "$OUT/serial.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/overlap" --output-format csv -- python3 "$REPO/bench.py" --no-cpu-baseline --sustain-seconds 0 --steps 20 --warmup 3 > "$OUT/overlap_bench.json" 2> "$OUT/overlap.err"
 cd "$REPO"
 for k in serial overlap; do
   f=$(ls "$OUT"/$k/*/*kernel_stats.csv | head -1); cp "$f" "$OUT/${k}_kernel_stats.csv"
