@@ -206,6 +206,7 @@ struct rt_ctx {
     size_t pinned_bytes = 0;
     uint32_t extend_waves = 8192;
     uint32_t refill_threshold = 16;
+    bool wave_bin = false;  // wavefront pipeline: rays regrouped by direction octant between bounces (RT_WAVE_BIN=1)
 };
 
 namespace {
@@ -300,7 +301,7 @@ void trace_frame(rt_ctx *c, const rt::TraceParams &p, int mode, bool aux, bool s
     else if (c->pipeline == 2)
         rt::launch_trace_regroup(p, mode, aux, stats, s);
     else
-        rt::launch_wavefront_frame(p, c->q, mode, aux, stats, c->extend_waves, c->refill_threshold, s);
+        rt::launch_wavefront_frame(p, c->q, mode, aux, stats, c->extend_waves, c->refill_threshold, c->wave_bin, s);
 }
 
 // Makes `stream` depend on everything queued on the trace streams and folds the odd frames' sum
@@ -656,6 +657,7 @@ static int create_impl(rt_ctx *c, int device) {
     // experiment knobs (defaults are the tuned values)
     if (const char *e = getenv("RT_PIPELINE")) c->pipeline = (strcmp(e, "wave") == 0) ? 1 : (strcmp(e, "regroup") == 0) ? 2 : 0;
     if (const char *e = getenv("RT_REFILL")) c->refill_threshold = (uint32_t)atoi(e);
+    if (const char *e = getenv("RT_WAVE_BIN")) c->wave_bin = atoi(e) != 0;
     if (const char *e = getenv("RT_EXTEND_WAVES")) c->extend_waves = (uint32_t)atoi(e);
     if (c->refill_threshold < 1u) c->refill_threshold = 1u;
     if (c->refill_threshold > 64u) c->refill_threshold = 64u;

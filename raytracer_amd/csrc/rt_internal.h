@@ -116,7 +116,7 @@ void launch_copy_raw32(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t
 void launch_trace(const TraceParams &p, int mode, bool aux, bool stats, bool leaf_steps, hipStream_t s);
 // one frame through the wavefront pipeline: generate, then per bounce extend + shade
 void launch_wavefront_frame(const TraceParams &p, const WaveQueues &q, int mode, bool aux, bool stats,
-                            uint32_t extend_waves, uint32_t refill_threshold, hipStream_t s);
+                            uint32_t extend_waves, uint32_t refill_threshold, bool bin_by_octant, hipStream_t s);
 // accumulate pass: acc = srgb(lin(acc) + (lin(sample) - lin(acc)) / (frames + 1))
 void launch_accumulate(const float4 *sample, float4 *acc, size_t npixels, float frames, hipStream_t s);
 // acc = srgb(sum / spp)

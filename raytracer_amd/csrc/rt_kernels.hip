@@ -1648,8 +1648,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_EXTEND_MIN_WAVES) void extend_kernel(D
 }
 
 // The rest of the loop body for every live slot, one lane per slot; the surviving ray replaces
-// the old one in place.
-template <int MODE, bool AUX, bool STATS>
+// the old one.  BIN = false: in place.  BIN = true (RT_WAVE_BIN=1): the 256 slots of the block are
+// rewritten grouped by the octant of the new ray's direction (a counting sort over the block: wave
+// ballots, one barrier), ended paths last, so that the traversal kernel's 64-slot chunks hold rays
+// that point the same way and no gaps; records move together, and the pixel index travels in the
+// ray record, so nothing else needs to know where a path sits.
+template <int MODE, bool AUX, bool STATS, bool BIN>
 __global__ __launch_bounds__(RT_BLOCK) void shade_kernel(TraceParams p, WaveQueues q, uint32_t n_slots,
                                                         uint32_t bounce_index) {
     const DevScene &sc = p.scene;
@@ -1657,14 +1661,17 @@ __global__ __launch_bounds__(RT_BLOCK) void shade_kernel(TraceParams p, WaveQueu
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nb = (uint32_t)p.bounces;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+    Path ps;
+    uint32_t pix = RT_DEAD;
+    bool alive = false, was_live = false;
     if (i < n_slots) {
         float4 r0 = q.rays[0][i * 2];
-        uint32_t pix = f2u(r0.w);
+        pix = f2u(r0.w);
         if (pix != RT_DEAD) {
+            was_live = true;
             float4 r1 = q.rays[0][i * 2 + 1];
             float2 h = q.hits[i];
             float4 s0 = q.paths[i * 2], s1 = q.paths[i * 2 + 1];
-            Path ps;
             ps.O = V(r0.x, r0.y, r0.z);
             ps.D = V(r1.x, r1.y, r1.z);
             ps.thr = V(s0.x, s0.y, s0.z);
@@ -1673,7 +1680,7 @@ __global__ __launch_bounds__(RT_BLOCK) void shade_kernel(TraceParams p, WaveQueu
             ps.ior = s1.w;
             bool exists;
             float thit;
-            bool alive = bounce<STATS>(sc, ps, h.x, f2u(h.y), bounce_index, exists, thit, st);
+            alive = bounce<STATS>(sc, ps, h.x, f2u(h.y), bounce_index, exists, thit, st);
             if (AUX && bounce_index == 0u) {
                 uint32_t *a = p.aux + (size_t)pix * 16;
                 a[0] = f2u(h.y);
@@ -1681,23 +1688,47 @@ __global__ __launch_bounds__(RT_BLOCK) void shade_kernel(TraceParams p, WaveQueu
                 a[2] = exists ? 1u : 0u;
             }
             alive = alive && (bounce_index + 1u < nb);
-            if (alive) {
-                q.rays[0][i * 2] = make_float4(ps.O.x, ps.O.y, ps.O.z, u2f(pix));
-                q.rays[0][i * 2 + 1] = make_float4(ps.D.x, ps.D.y, ps.D.z, 0.f);
-                q.paths[i * 2] = make_float4(ps.thr.x, ps.thr.y, ps.thr.z, u2f(ps.rng));
-                q.paths[i * 2 + 1] = make_float4(ps.light.x, ps.light.y, ps.light.z, ps.ior);
-            } else {
+            if (!alive) {
                 write_pixel<MODE>(p, pix, ps.light);
                 if (AUX) write_aux_tail(p.aux, pix, ps, bounce_index + 1u);
-                q.rays[0][i * 2] = make_float4(0.f, 0.f, 0.f, u2f(RT_DEAD));
             }
+        }
+    }
+    size_t dst = i;
+    if (BIN) {
+        __shared__ uint32_t wave_count[RT_BLOCK / 64][9];
+        const uint32_t wave = threadIdx.x >> 6;
+        const uint32_t key = alive ? ((ps.D.x < 0.0f ? 1u : 0u) | (ps.D.y < 0.0f ? 2u : 0u) | (ps.D.z < 0.0f ? 4u : 0u)) : 8u;
+        uint32_t rank_in_wave = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 9u; k++) {
+            const unsigned long long m = __ballot(key == k);
+            if (key == k)
+                rank_in_wave = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (lane == 0u) wave_count[wave][k] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();  // every record of the block has been read by now: the block's slots may be rewritten
+        uint32_t base = 0;
+        for (uint32_t k = 0; k < 9u; k++)
+            for (uint32_t w = 0; w < RT_BLOCK / 64u; w++)
+                if (k < key || (k == key && w < wave)) base += wave_count[w][k];
+        dst = (size_t)blockIdx.x * RT_BLOCK + base + rank_in_wave;
+    }
+    if (i < n_slots) {
+        if (alive) {
+            q.rays[0][dst * 2] = make_float4(ps.O.x, ps.O.y, ps.O.z, u2f(pix));
+            q.rays[0][dst * 2 + 1] = make_float4(ps.D.x, ps.D.y, ps.D.z, 0.f);
+            q.paths[dst * 2] = make_float4(ps.thr.x, ps.thr.y, ps.thr.z, u2f(ps.rng));
+            q.paths[dst * 2 + 1] = make_float4(ps.light.x, ps.light.y, ps.light.z, ps.ior);
+        } else if (was_live || BIN) {
+            q.rays[0][dst * 2] = make_float4(0.f, 0.f, 0.f, u2f(RT_DEAD));
         }
     }
     if (STATS) flush_counters<true>(p.counters, lane, 0u, st);
 }
 
 void launch_wavefront_frame(const TraceParams &p, const WaveQueues &q, int mode, bool aux, bool stats,
-                            uint32_t extend_waves, uint32_t refill_threshold, hipStream_t s) {
+                            uint32_t extend_waves, uint32_t refill_threshold, bool bin_by_octant, hipStream_t s) {
     uint32_t per = (p.ntiles + 7u) / 8u;
     if (per == 0) return;
     const uint32_t nb_raw = (uint32_t)p.bounces;
@@ -1723,7 +1754,11 @@ void launch_wavefront_frame(const TraceParams &p, const WaveQueues &q, int mode,
         else
             hipLaunchKernelGGL((extend_kernel<false>), dim3(egroups), dim3(RT_BLOCK), 0, s, p.scene, q, n_slots,
                                refill_threshold, p.counters, (uint32_t *)nullptr);
-#define S(M, A, T) hipLaunchKernelGGL((shade_kernel<M, A, T>), tgrid, block, 0, s, p, q, n_slots, b)
+#define S(M, A, T)                                                                                       \
+    do {                                                                                                 \
+        if (bin_by_octant) hipLaunchKernelGGL((shade_kernel<M, A, T, true>), tgrid, block, 0, s, p, q, n_slots, b);  \
+        else hipLaunchKernelGGL((shade_kernel<M, A, T, false>), tgrid, block, 0, s, p, q, n_slots, b);   \
+    } while (0)
         if (mode == 0) {
             if (aux && stats) S(0, true, true);
             else if (aux) S(0, true, false);

@@ -777,20 +777,23 @@ def test_traversal_variant_can_be_fixed_per_context():
         r.close()
 
 
-@pytest.mark.parametrize("layout", [1, 2])
-def test_node_record_layouts_change_no_pixel(layout):
+@pytest.mark.parametrize("knobs", [{"RT_NODE_LAYOUT": "1"}, {"RT_NODE_LAYOUT": "2"},
+                                   {"RT_PIPELINE": "wave", "RT_WAVE_BIN": "1"}])
+def test_experiment_knobs_change_no_pixel(knobs):
     """RT_NODE_LAYOUT (depth-first subtrees / three-level treelets below the LDS copy instead of
-    breadth-first order) renumbers the device node records only: images and first hits stay the
+    breadth-first order) renumbers the device node records only, and RT_WAVE_BIN regroups the
+    wavefront pipeline's rays by direction octant between bounces: images and first hits stay the
     reference shader's."""
     import os
 
     from raytracer_amd.renderer import Renderer
 
-    os.environ["RT_NODE_LAYOUT"] = str(layout)
+    os.environ.update(knobs)
     try:
         r = Renderer(device=0, singleton=False)
     finally:
-        os.environ.pop("RT_NODE_LAYOUT", None)
+        for k in knobs:
+            os.environ.pop(k, None)
     try:
         for scene, tag in (("gally", "small_160x88_b4"), ("matlab", "small_160x88_b6")):
             rec = json.loads((GOLDEN / scene / f"{tag}.json").read_text())
