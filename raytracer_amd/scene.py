@@ -187,7 +187,15 @@ def quad_to_triangles(center, width, height, normal):
 
 
 def read_obj(path) -> np.ndarray:
-    """(n,3,3) float32 triangles of a Wavefront OBJ, faces in file order, polygons as fans."""
+    """(n,3,3) float32 triangles of a Wavefront OBJ: faces in file order, polygons as fans from
+    their first vertex, `v/vt/vn` tokens reduced to the position index, negative indices relative
+    to the vertices read so far; every other statement (vt, vn, g, o, s, usemtl, mtllib) is skipped
+    -- the reference gives a mesh ONE material from its scene file and ignores MTL files
+    (src/scene/scene.py:170,181).  The reference reads meshes with trimesh
+    (src/model/model.py:40-57), which is not available here: for a file of triangles with one
+    material trimesh keeps this order too; for a file with several `usemtl` groups it returns one
+    geometry per material, so the reference's triangle order is then grouped by material, which
+    this reader does not imitate (ids differ, images do not)."""
     verts: list[tuple[float, float, float]] = []
     faces: list[tuple[int, int, int]] = []
     with Path(path).open() as f:
@@ -204,7 +212,59 @@ def read_obj(path) -> np.ndarray:
                     faces.append((idx[0], idx[k], idx[k + 1]))
     va = np.array(verts, dtype=np.float32).reshape(-1, 3)
     fa = np.array(faces, dtype=np.int64).reshape(-1, 3)
+    if fa.size and (fa.min() < 0 or fa.max() >= va.shape[0]):
+        raise ValueError(f"{path}: a face refers to vertex {int(fa.max()) + 1} of {va.shape[0]}")
     return va[fa]
+
+
+def write_obj(path, meshes, styles=("plain", "full", "negative", "normal_only")) -> int:
+    """Writes triangle soups as a Wavefront OBJ that read_obj turns back into exactly the same
+    triangles in the same order.  `meshes`: list of ((n,3,3) float32 triangles, material index).
+    Every mesh becomes a group (`g`, `usemtl`) with its vertices deduplicated; consecutive triangles
+    that form a fan (same first vertex, the next one starting where the last ended) are merged
+    into one polygon face, so meshes stored quad by quad come out as quads.  The face syntax
+    cycles through `styles` mesh by mesh: "plain" `f a b c`, "full" `f a/t/n ...` with vt and vn
+    lines, "negative" relative indices, "normal_only" `f a//n`.  Coordinates are written with nine
+    significant digits, which a float32 survives.  Returns the number of faces written."""
+    nv = 0      # vertices written so far
+    nfaces = 0
+    with Path(path).open("w") as f:
+        f.write("# written by raytracer_amd.scene.write_obj\nmtllib scene.mtl\n")
+        for k, (tris, material) in enumerate(meshes):
+            tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 3, 3)
+            style = styles[k % len(styles)]
+            flat = tris.reshape(-1, 3)
+            uniq, inv = np.unique(flat.view(np.uint32), axis=0, return_inverse=True)
+            uniq = uniq.view(np.float32)
+            inv = inv.reshape(-1, 3)
+            f.write(f"g mesh{k}\nusemtl material{int(material)}\n")
+            for v in uniq:
+                f.write("v %.9g %.9g %.9g\n" % (v[0], v[1], v[2]))
+            if style in ("full", "normal_only"):
+                f.write("vn 0 1 0\n")
+            if style == "full":
+                f.write("vt 0.5 0.5\n")
+            n_here = uniq.shape[0]
+
+            def tok(local):
+                if style == "negative":
+                    return str(int(local) - n_here)
+                g = nv + int(local) + 1
+                return f"{g}/1/1" if style == "full" else f"{g}//1" if style == "normal_only" else str(g)
+
+            i = 0
+            while i < inv.shape[0]:
+                poly = [inv[i, 0], inv[i, 1], inv[i, 2]]
+                j = i + 1
+                # a fan continues while the next triangle is (first, last of this one, something new)
+                while j < inv.shape[0] and inv[j, 0] == poly[0] and inv[j, 1] == poly[-1] and len(poly) < 8:
+                    poly.append(inv[j, 2])
+                    j += 1
+                f.write("f " + " ".join(tok(p) for p in poly) + "\n")
+                nfaces += 1
+                i = j
+            nv += n_here
+    return nfaces
 
 
 def build_qbvh(aabb_min, aabb_max, types, indices):

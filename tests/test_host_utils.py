@@ -91,3 +91,29 @@ def test_host_tree_builders_under_address_and_ub_sanitizers(tmp_path):
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
     assert "0 failed" in run.stdout
+
+
+def test_obj_writer_and_reader_round_trip(tmp_path):
+    """write_obj / read_obj: every face syntax (plain, v/vt/vn, v//vn, negative indices), polygons as
+    fans, groups and usemtl lines skipped; the triangles come back bit for bit in file order."""
+    from raytracer_amd import scene as S, synth
+
+    _, meshes = synth.sponza_synth(0.02)
+    g = meshes[0][0]
+    n = g.shape[0] // 2
+    meshes = meshes[:9] + [(np.stack([g[:n], g[n:]], 1).reshape(-1, 3, 3), 2)]
+    path = tmp_path / "m.obj"
+    nfaces = S.write_obj(path, meshes)
+    want = np.concatenate([m for m, _ in meshes])
+    got = S.read_obj(path)
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert nfaces < want.shape[0]
+    # a pentagon with texture indices and a trailing comment line
+    (tmp_path / "p.obj").write_text("o pent\nv 0 0 0\nv 1 0 0\nv 1.5 1 0\nv 0.5 2 0\nv -0.5 1 0\nvt 0 0\n"
+                                    "s off\nf 1/1 2/1 3/1 4/1 5/1\n# end\n")
+    tri = S.read_obj(tmp_path / "p.obj")
+    assert tri.shape == (3, 3, 3) and np.array_equal(tri[:, 0], np.zeros((3, 3), np.float32))
+    assert np.array_equal(tri[2, 2], np.array([-0.5, 1, 0], np.float32))
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nf 1 2 3\n")
+    with pytest.raises(ValueError):
+        S.read_obj(tmp_path / "bad.obj")

@@ -93,3 +93,54 @@ def damaged_gally_materials():
     if sph.shape[0]:
         sph[0, 5] = 0x7FFFFFFF
     return tris, sph
+
+
+def spine_tree(depth: int):
+    """A hand-made scene whose traversal stack grows by three entries per level: `depth` spine nodes,
+    each with the next spine node in slot 0 and three small subtrees (an inner node over four
+    spheres) in slots 1..3, every child box being the whole scene box with the camera inside.  All
+    entry distances are 0, so the sort keeps the slot order, slot 0 is popped first and the three
+    siblings of every level wait on the stack: the deepest pop happens at 3 * depth + 1 entries.
+    (With the reference's builder a tree this deep needs millions of primitives; its shader's own
+    stack has 32 entries and no guard, so beyond depth 10 the reference itself is undefined.)
+    Returns (spheres (n, 8) uint32, nodes (m, 16) uint32, materials (2, 3) uint32, 25 uniform floats)."""
+    from raytracer_amd import scene as S
+    from raytracer_amd.camera import Camera
+
+    full = np.uint32(0xFFFF0000)
+    spheres, nodes = [], []
+
+    def sphere(i):
+        # a loose spiral in front of the default camera (which looks along -x from (8, 1.5, 0))
+        a = 0.61803 * i
+        return [float(2.0 - 0.035 * i), float(1.5 + 2.2 * np.sin(a) * (0.3 + (i % 7) / 9.0)),
+                float(2.8 * np.cos(a) * (0.3 + (i % 5) / 7.0))], 0.16 + 0.02 * (i % 3)
+
+    def leaf_node():
+        words = np.zeros(16, np.uint32)
+        words[0:12] = full
+        for k in range(4):
+            words[12 + k] = (1 << 30) | len(spheres)
+            spheres.append(sphere(len(spheres)))
+        return words
+
+    # node numbering: spine node k is 4k, its three subtrees 4k+1 .. 4k+3; the spine ends in a leaf node
+    for k in range(depth):
+        words = np.zeros(16, np.uint32)
+        words[0:12] = full
+        words[12] = (3 << 30) | (4 * (k + 1))
+        for j in range(1, 4):
+            words[12 + j] = (3 << 30) | (4 * k + j)
+        nodes.append(words)
+        for j in range(1, 4):
+            nodes.append(leaf_node())
+    nodes.append(leaf_node())
+    centers = np.array([c for c, _ in spheres], np.float32)
+    radii = [r for _, r in spheres]
+    sph, _, _ = S.pack_spheres(centers, radii, [1] * len(radii))
+    mats = np.concatenate([S.pack_material(color=[1.0, 1.0, 1.0], emission=[1.0, 1.0, 1.0, 0.0]),
+                           S.pack_material(color=[0.9, 0.5, 0.3], emission=[1.0, 0.8, 0.6, 2.0], smoothness=0.4)])
+    inv_vp, eye = Camera().uniforms_f32()
+    u = np.concatenate([inv_vp, eye, [-6.0, -3.0, -5.0], [16.0, 9.0, 10.0]]).astype(np.float32)
+    return (np.frombuffer(sph.tobytes(), np.uint32).reshape(-1, 8), np.array(nodes, np.uint32), 
+            np.frombuffer(mats.tobytes(), np.uint32).reshape(-1, 3), u)
