@@ -410,42 +410,6 @@ __device__ __forceinline__ float4 ld4(GlobalNodes p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// The seven 16-byte loads of one step: the first 112 bytes of the workgroup's LDS copy of a node
-// (lanes with in_lds set; lds_addr = byte address within LDS) or of a 128-byte line in global memory
-// (the other lanes).  ONE assembly statement issues both kinds, each under its own execution mask,
-// so that in a wavefront whose lanes split between the two cases both kinds are in flight together
-// (left to the compiler, the two cases are the arms of a branch that write the same registers, and
-// it waits for all global loads before it issues the LDS reads), and waits for all of them before
-// it ends: the destination registers never exist as C++ values while a load is still in flight, so
-// nothing the compiler may insert (a copy at a control-flow merge, a spill) can read them early.
-// (Waiting for the seven vectors one by one between the slab tests of a node, so that arithmetic
-// starts while the later ones arrive, measured the same: they come from one cache line.)
-__device__ __forceinline__ void line_loads(bool in_lds, uint32_t lds_addr, uintptr_t line, vec4f &a0, vec4f &a1, vec4f &a2,
-                                           vec4f &a3, vec4f &a4, vec4f &a5, vec4f &a6) {
-    const unsigned long long lds_lanes = __ballot(in_lds);
-    unsigned long long saved;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_and_b64 exec, %[sv], %[m]\n\t"
-        "s_cbranch_execz .Lno_lds_lanes_%=\n\t"
-        "ds_read_b128 %0, %[la]\n\tds_read_b128 %1, %[la] offset:16\n\tds_read_b128 %2, %[la] offset:32\n\t"
-        "ds_read_b128 %3, %[la] offset:48\n\tds_read_b128 %4, %[la] offset:64\n\tds_read_b128 %5, %[la] offset:80\n\t"
-        "ds_read_b128 %6, %[la] offset:96\n"
-        ".Lno_lds_lanes_%=:\n\t"
-        "s_andn2_b64 exec, %[sv], %[m]\n\t"
-        "s_cbranch_execz .Lno_global_lanes_%=\n\t"
-        "global_load_dwordx4 %0, %[ga], off\n\tglobal_load_dwordx4 %1, %[ga], off offset:16\n\t"
-        "global_load_dwordx4 %2, %[ga], off offset:32\n\tglobal_load_dwordx4 %3, %[ga], off offset:48\n\t"
-        "global_load_dwordx4 %4, %[ga], off offset:64\n\tglobal_load_dwordx4 %5, %[ga], off offset:80\n\t"
-        "global_load_dwordx4 %6, %[ga], off offset:96\n"
-        ".Lno_global_lanes_%=:\n\t"
-        "s_mov_b64 exec, %[sv]\n\t"
-        "s_waitcnt vmcnt(0) lgkmcnt(0)"
-        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), [sv] "=&s"(saved)
-        : [m] "s"(lds_lanes), [la] "v"(lds_addr), [ga] "v"(line)
-        : "memory");
-}
-
 // Issues the loads of node ni.  TOP > 0: the first TOP nodes (breadth-first numbering, i.e. the top
 // levels of the tree) are read from the workgroup's LDS copy `top` instead of through the vector
 // memory pipeline, which is what bounds this kernel.
@@ -470,10 +434,41 @@ __device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeR
         // Written in assembly so that the two cases may be in flight together: in a wavefront whose
         // lanes split between them the compiler would wait for all global loads before it issues the
         // LDS reads, because both write the same registers (in different lanes, which it cannot know).
+        // Between these statements and the waits below a0..a6 hold data still in flight, which the
+        // compiler does not know either: tools/check_isa.py (make check-isa, part of the build)
+        // verifies on the generated code that both arms got the same registers and that nothing it
+        // placed in between (a copy at the merge, a spill) touches them.  (Issuing both kinds from ONE
+        // statement under explicit execution masks, which needs no such check, costs 1.3 % of a
+        // frame on cache-resident scenes.)
         vec4f a0, a1, a2, a3, a4, a5, a6;
-        const bool in_lds = ni < (uint32_t)TOP;
-        line_loads(in_lds, (uint32_t)(uintptr_t)top + ni * (RT_TOP_STRIDE * 16u),
-                   in_lds ? (uintptr_t)0 : (uintptr_t)(sc.nodes + (size_t)ni * kNodeVec), a0, a1, a2, a3, a4, a5, a6);
+        if (ni < (uint32_t)TOP) {
+            const uint32_t addr = (uint32_t)(uintptr_t)top + ni * (RT_TOP_STRIDE * 16u);
+            asm volatile(
+                "ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:32\n\t"
+                "ds_read_b128 %3, %7 offset:48\n\tds_read_b128 %4, %7 offset:64\n\tds_read_b128 %5, %7 offset:80\n\t"
+                "ds_read_b128 %6, %7 offset:96"
+                : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6)
+                : "v"(addr)
+                : "memory");
+        } else {
+            const float4 *np = sc.nodes + (size_t)ni * kNodeVec;
+            asm volatile(
+                "global_load_dwordx4 %0, %7, off\n\tglobal_load_dwordx4 %1, %7, off offset:16\n\t"
+                "global_load_dwordx4 %2, %7, off offset:32\n\tglobal_load_dwordx4 %3, %7, off offset:48\n\t"
+                "global_load_dwordx4 %4, %7, off offset:64\n\tglobal_load_dwordx4 %5, %7, off offset:80\n\t"
+                "global_load_dwordx4 %6, %7, off offset:96"
+                : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6)
+                : "v"(np)
+                : "memory");
+        }
+        // either kind returns in order: vector k has arrived when at most 6 - k of its kind are outstanding
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(6)" : "+v"(a0));
+        asm volatile("s_waitcnt vmcnt(5) lgkmcnt(5)" : "+v"(a1));
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(4)" : "+v"(a2));
+        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(3)" : "+v"(a3));
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(2)" : "+v"(a4));
+        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(1)" : "+v"(a5));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a6));
         nd.lox = make_float4(a0.x, a0.y, a0.z, a0.w), nd.hix = make_float4(a1.x, a1.y, a1.z, a1.w);
         nd.loy = make_float4(a2.x, a2.y, a2.z, a2.w), nd.hiy = make_float4(a3.x, a3.y, a3.z, a3.w);
         nd.loz = make_float4(a4.x, a4.y, a4.z, a4.w), nd.hiz = make_float4(a5.x, a5.y, a5.z, a5.w);
@@ -713,15 +708,40 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
         const uint32_t type = cur >> 30, idx = cur & 0x3FFFFFFFu;
         const uint32_t ni = min(idx, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
         const bool in_lds = type == 3u && ni < (uint32_t)TOP;
-        vec4f a0, a1, a2, a3, a4, a5, a6;
+        vec4f a0, a1, a2, a3, a4, a5, a6;  // in flight until the waits below: see node_load and tools/check_isa.py
         uintptr_t rec = 0;  // address of the item's record
-        if (!in_lds) {
+        if (in_lds) {
+            const uint32_t addr = (uint32_t)(uintptr_t)top + ni * (RT_TOP_STRIDE * 16u);
+            asm volatile(
+                "ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:32\n\t"
+                "ds_read_b128 %3, %7 offset:48\n\tds_read_b128 %4, %7 offset:64\n\tds_read_b128 %5, %7 offset:80\n\t"
+                "ds_read_b128 %6, %7 offset:96"
+                : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6)
+                : "v"(addr)
+                : "memory");
+        } else {
             if (type == 3u) rec = (uintptr_t)(sc.nodes + (size_t)ni * kNodeVec);
             else if (type == 0u) rec = (uintptr_t)(sc.tris + (size_t)min(idx, sc.n_tris) * kTriVec);
             else if (type == 1u) rec = (uintptr_t)(sc.spheres + (size_t)min(idx, sc.n_spheres) * kSphereVec);
             else rec = (uintptr_t)(sc.boxes + (size_t)min(idx, sc.n_boxes) * 2);
+            const float4 *line = reinterpret_cast<const float4 *>(rec & ~(uintptr_t)127);
+            asm volatile(
+                "global_load_dwordx4 %0, %7, off\n\tglobal_load_dwordx4 %1, %7, off offset:16\n\t"
+                "global_load_dwordx4 %2, %7, off offset:32\n\tglobal_load_dwordx4 %3, %7, off offset:48\n\t"
+                "global_load_dwordx4 %4, %7, off offset:64\n\tglobal_load_dwordx4 %5, %7, off offset:80\n\t"
+                "global_load_dwordx4 %6, %7, off offset:96"
+                : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6)
+                : "v"(line)
+                : "memory");
         }
-        line_loads(in_lds, (uint32_t)(uintptr_t)top + ni * (RT_TOP_STRIDE * 16u), rec & ~(uintptr_t)127, a0, a1, a2, a3, a4, a5, a6);
+        // either kind returns in order: vector k has arrived when at most 6 - k of its kind are outstanding
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(6)" : "+v"(a0));
+        asm volatile("s_waitcnt vmcnt(5) lgkmcnt(5)" : "+v"(a1));
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(4)" : "+v"(a2));
+        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(3)" : "+v"(a3));
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(2)" : "+v"(a4));
+        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(1)" : "+v"(a5));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a6));
 #define F4(a) make_float4(a.x, a.y, a.z, a.w)
         if (type == 3u) {
             if (STATS) st.nodes++;

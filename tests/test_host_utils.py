@@ -117,3 +117,52 @@ def test_obj_writer_and_reader_round_trip(tmp_path):
     (tmp_path / "bad.obj").write_text("v 0 0 0\nf 1 2 3\n")
     with pytest.raises(ValueError):
         S.read_obj(tmp_path / "bad.obj")
+
+
+def test_isa_checker_flags_what_it_is_there_for():
+    """tools/check_isa.py on fabricated listings: the shape the compiler produces today passes; a copy
+    at the control-flow merge, a use after too early a wait, a spill, or arms that load into
+    different registers are reported.  (The check of the real code runs at build time.)"""
+    import sys
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import check_isa as c
+
+    good = """\t;;#ASMSTART
+\tglobal_load_dwordx4 v[2:5], v[36:37], off
+\tglobal_load_dwordx4 v[6:9], v[36:37], off offset:16
+\t;;#ASMEND
+\ts_andn2_saveexec_b64 s[0:1], s[4:5]
+\tv_mul_lo_u32 v2, v48, s2
+\t;;#ASMSTART
+\tds_read_b128 v[2:5], v34
+\tds_read_b128 v[6:9], v34 offset:16
+\t;;#ASMEND
+\tv_mov_b64_e32 v[50:51], 0
+\ts_or_b64 exec, exec, s[0:1]
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(1) lgkmcnt(1)
+\t;;#ASMEND
+\tv_add_f32 v10, v2, v3
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(0) lgkmcnt(0)
+\t;;#ASMEND
+\tv_add_f32 v10, v6, v7""".splitlines()
+
+    def run(lines):
+        return c.check_function("k", list(enumerate(lines, 1)))
+
+    assert run(good) == []
+    bad = list(good)
+    bad.insert(12, "\tv_mov_b32_e32 v20, v6")               # a copy at the merge, before any wait
+    assert len(run(bad)) == 1 and "v_mov_b32_e32 v20, v6" in run(bad)[0]
+    bad = list(good)
+    bad[15] = "\tv_add_f32 v10, v6, v3"                     # the second vector used after the first wait only
+    assert len(run(bad)) == 1
+    bad = list(good)
+    bad.insert(11, "\tscratch_store_dword off, v7, s32")    # a spill of a register in flight
+    assert len(run(bad)) == 1
+    bad = list(good)
+    bad[8] = "\tds_read_b128 v[12:15], v34 offset:16"       # the arms disagree: a merge would need copies
+    assert any("different registers" in m for m in run(bad))
+    assert len(run(good[:12])) == 1                         # loads that are never waited for
