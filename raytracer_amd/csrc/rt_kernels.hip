@@ -523,13 +523,21 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
         const float bx = (nd.lox.x - O.x) * ID.x, by = (nd.lox.y - O.y) * ID.y, bz = (nd.lox.z - O.z) * ID.z;
         const uint32_t qlx = f2u(nd.hix.x), qhx = f2u(nd.hix.y), qly = f2u(nd.hix.z), qhy = f2u(nd.hix.w),
                        qlz = f2u(nd.loy.x), qhz = f2u(nd.loy.y);
+        // The plane a ray enters a slab through is the low one where the direction is positive and the
+        // high one where it is negative: lo code <= hi code and the scale is positive, so
+        // fma(code, a, b) is monotone in the code and min(t_lo, t_hi) / max(t_lo, t_hi) are simply the
+        // one or the other, bit for bit (ID is finite and non-zero here, so nothing is NaN).  Choosing
+        // the code words once per node saves the six min / max per child.
+        const bool px = ID.x >= 0.0f, py = ID.y >= 0.0f, pz = ID.z >= 0.0f;
+        const uint32_t nx = px ? qlx : qhx, fx = px ? qhx : qlx, ny = py ? qly : qhy, fy = py ? qhy : qly,
+                       nz = pz ? qlz : qhz, fz = pz ? qhz : qlz;
 #define FSLAB(SH, M, KEY)                                                                                  \
     {                                                                                                       \
-        float t1x = __builtin_fmaf((float)((qlx >> SH) & 0xFFu), ax, bx), t2x = __builtin_fmaf((float)((qhx >> SH) & 0xFFu), ax, bx); \
-        float t1y = __builtin_fmaf((float)((qly >> SH) & 0xFFu), ay, by), t2y = __builtin_fmaf((float)((qhy >> SH) & 0xFFu), ay, by); \
-        float t1z = __builtin_fmaf((float)((qlz >> SH) & 0xFFu), az, bz), t2z = __builtin_fmaf((float)((qhz >> SH) & 0xFFu), az, bz); \
-        float tN = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));            \
-        float tF = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z)) * 1.0000004f;            \
+        float tnx = __builtin_fmaf((float)((nx >> SH) & 0xFFu), ax, bx), tfx = __builtin_fmaf((float)((fx >> SH) & 0xFFu), ax, bx); \
+        float tny = __builtin_fmaf((float)((ny >> SH) & 0xFFu), ay, by), tfy = __builtin_fmaf((float)((fy >> SH) & 0xFFu), ay, by); \
+        float tnz = __builtin_fmaf((float)((nz >> SH) & 0xFFu), az, bz), tfz = __builtin_fmaf((float)((fz >> SH) & 0xFFu), az, bz); \
+        float tN = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));                                                \
+        float tF = fminf(fminf(tfx, tfy), tfz) * 1.0000004f;                                                \
         KEY = tN;                                                                                           \
         M = ((tN <= tF) && (tN < best)) ? M : kSkip; /* an empty slot is kSkip already */                   \
     }
