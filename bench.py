@@ -464,6 +464,8 @@ def worker(args):
     rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
     # the host driver only supports dmabuf IPC; RCCL's peer buffers need this set before HIP starts
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")   # RCCL's own reason, should the communicator fail to form
 
     from raytracer_amd import dist as D
     from raytracer_amd.camera import Camera
