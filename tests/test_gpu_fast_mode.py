@@ -148,3 +148,55 @@ def test_fast_mode_mean_image_is_within_monte_carlo_noise_of_parity_mode(rendere
     psnr = 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
     print(f"fast vs parity, sRGB mean image: max abs {err.max():.4f}, PSNR {psnr:.1f} dB")
     assert psnr >= 40.0
+
+
+def test_fast_mode_on_fresh_random_scenes(renderer):
+    """Thirty random scenes (all four primitive kinds, cameras anywhere; every sixth dense with
+    hundreds of spheres and boxes): the fast-mode kernel against the oracle's traversal of the tree
+    the library built -- image, end-of-path state, work counters -- and never a lost first hit
+    against the default mode."""
+    import sys
+
+    sys.path.insert(0, str(GOLDEN.parents[1] / "oracle"))
+    import gen_fuzz as F
+
+    rng = np.random.default_rng(4242)
+    w, h = 96, 64
+    bad = []
+    for case in range(30):
+        if case % 6 == 5:
+            scene, cam = F.dense_scene(rng, 9500 + case, int(rng.integers(50, 400)), int(rng.integers(0, 200)), 3)
+        else:
+            scene, cam = F.random_scene(rng, 9500 + case)
+        b = S.build_scene(scene)
+        inv_vp, eye = F.camera_uniforms(cam)
+        b.upload(renderer)
+        renderer.set_uniforms(inv_vp, eye)
+        u = np.concatenate([inv_vp, eye, b.scene_min, b.scene_extent]).astype(np.float32)
+        sc = O.OracleScene(bvh=b.bvh.tobytes(), tris=b.triangles.tobytes(), spheres=b.spheres.tobytes(),
+                           mats=b.materials.tobytes(), uniforms=u, boxes=b.boxes.tobytes(), planes=b.planes.tobytes())
+        bounces, frame = int(rng.integers(1, 7)), int(rng.integers(0, 1000))
+        render_frame(renderer, w, h, frame, bounces, aux=True)
+        paux = renderer.read_aux()
+        renderer.fast_mode = True
+        try:
+            renderer.reset_stats()
+            img = render_frame(renderer, w, h, frame, bounces, aux=True, stats=True)
+            aux, st, nodes = renderer.read_aux(), renderer.stats(), renderer.fast_bvh()
+        finally:
+            renderer.fast_mode = False
+        try:
+            O.set_fast_bvh(nodes)
+            ref, raux, cnt = sc.render(w, h, frame, bounces, want_primary=True, want_counters=True)
+        finally:
+            O.set_fast_bvh(None)
+        if not (np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and np.array_equal(aux, raux)):
+            bad.append((case, "oracle"))
+        if any(st[k] != cnt[k] for k in ("rays", "nodes", "tri_tests", "sphere_tests", "box_tests")):
+            bad.append((case, "counters"))
+        # first hits against the default mode: none lost, none farther (planes are outside both trees)
+        tr, tf = paux[..., 1].view(np.float32), aux[..., 1].view(np.float32)
+        hp, hf = paux[..., 2] == 1, aux[..., 2] == 1
+        if np.any(hp & ~hf) or np.any(tf[hp & hf] > tr[hp & hf] + 2e-6 * np.maximum(1.0, tr[hp & hf])):
+            bad.append((case, "lost or farther first hit"))
+    assert not bad, bad

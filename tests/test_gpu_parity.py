@@ -308,6 +308,47 @@ def test_random_scenes_match_reference_shader(renderer):
             assert sha(renderer.read_accumulation()) == acc_rec["acc_sha256_per_frame"][f], (name, f)
 
 
+def test_fresh_random_scenes_match_the_oracle(renderer):
+    """Sixty more random scenes from the generator the llvmpipe-pinned cases were drawn with (other
+    seeds; sparse ones with all four primitive kinds and cameras anywhere, and dense ones with
+    hundreds of small spheres and boxes), built by the host pipeline: image, first hit, end-of-path
+    state and every work counter against the oracle, which is itself pinned on those cases."""
+    import sys
+
+    sys.path.insert(0, str(GOLDEN.parents[1] / "oracle"))
+    import gen_fuzz as F   # scene generator only: nothing of the reference is needed to draw scenes
+    from raytracer_amd import scene as S
+
+    rng = np.random.default_rng(777)
+    w, h = 96, 64
+    bad = []
+    for case in range(60):
+        if case % 6 == 5:
+            scene, cam = F.dense_scene(rng, 9000 + case, int(rng.integers(50, 400)), int(rng.integers(0, 200)), 3)
+        else:
+            scene, cam = F.random_scene(rng, 9000 + case)
+        b = S.build_scene(scene)
+        inv_vp, eye = F.camera_uniforms(cam)
+        b.upload(renderer)
+        renderer.set_uniforms(inv_vp, eye)
+        u = np.concatenate([inv_vp, eye, b.scene_min, b.scene_extent]).astype(np.float32)
+        sc = O.OracleScene(bvh=b.bvh.tobytes(), tris=b.triangles.tobytes(), spheres=b.spheres.tobytes(),
+                           mats=b.materials.tobytes(), uniforms=u, boxes=b.boxes.tobytes(), planes=b.planes.tobytes())
+        bounces = int(rng.integers(1, 9))
+        frame = int(rng.integers(0, 1000))
+        renderer.reset_stats()
+        img = render_frame(renderer, w, h, frame, bounces, aux=True, stats=True)
+        aux, st = renderer.read_aux(), renderer.stats()
+        ref, raux, cnt = sc.render(w, h, frame, bounces, want_primary=True, want_counters=True)
+        if not np.array_equal(img.view(np.uint32), ref.view(np.uint32)):
+            bad.append((case, "image"))
+        if not np.array_equal(aux, raux):
+            bad.append((case, "state"))
+        if any(st[k] != cnt[k] for k in ("rays", "nodes", "tri_tests", "sphere_tests", "box_tests", "max_stack")):
+            bad.append((case, "counters"))
+    assert not bad, bad
+
+
 def test_the_reference_loaders_own_update_ssbo_arguments(renderer):
     """The arrays exactly as the reference's load_scene hands them to Renderer.update_ssbo
     (scene.py:62,97,121-122,191-193): structured dtypes, materials of shape (n,), spheres and
