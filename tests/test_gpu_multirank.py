@@ -109,3 +109,24 @@ def test_bench_rehearsal_with_eight_ranks_carries_the_diagnostics():
     assert out["value"] > 0 and out["ms_per_step"] > 0
     # weak scaling: every rank rendered its own frames of the same image
     assert abs(out["config"]["rays_per_frame"] * 8 * 3 / (out["value"] * 1e6 * out["ms_per_step"] * 3e-3) - 1) < 0.05
+
+
+def test_bench_c5_rehearsal_with_four_ranks_tile_and_sample_shards():
+    """bench.py --config c5 --gpus 4 end to end (two tile shards x two sample shards, the four ranks
+    sharing this GPU, collectives through host files): the strong-scaling line with its per-rank
+    render times, reduce time and imbalance."""
+    import json
+    import os
+
+    env = dict(os.environ, RT_BENCH_REHEARSE="1")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--config", "c5", "--steps", "1", "--warmup", "1",
+                        "--width", "640", "--height", "360", "--spp", "8", "--detail", "0.05"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 4 and out["scaling"] == "strong" and out["rccl_ranks"] == 4
+    assert "2 tile shard(s)" in out["config"]["parallelism"] and "x 2 sample shard(s)" in out["config"]["parallelism"]
+    assert len(out["per_rank_render_ms"]) == 4 and all(t > 0 for t in out["per_rank_render_ms"])
+    assert out["imbalance_max_over_mean"] >= 1.0 and out["stack_overflows"] == 0 and out["value"] > 0
+    # every pixel-sample of the image was rendered exactly once across the ranks: rays of a 640x360 8-spp image
+    assert 640 * 360 * 8 < out["value"] * 1e6 * out["ms_per_step"] * 1e-3 < 640 * 360 * 8 * 4.0
