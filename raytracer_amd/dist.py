@@ -265,11 +265,14 @@ class Comm:
         self.all_reduce([1.0])
 
     def gather(self, values) -> np.ndarray:
-        """(world, k) array of every rank's k float64 values, on every rank (k * world <= 64)."""
+        """(world, k) array of every rank's k float64 values, on every rank."""
         v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
         slots = np.zeros((self.world, v.size))
         slots[self.rank] = v
-        return self.all_reduce(slots.reshape(-1), "sum").reshape(self.world, v.size)
+        flat, out = slots.reshape(-1), []
+        for i in range(0, flat.size, 64):   # one scalar all-reduce carries at most 64 values
+            out.append(self.all_reduce(flat[i:i + 64], "sum"))
+        return np.concatenate(out).reshape(self.world, v.size)
 
     def info(self) -> tuple[int, int]:
         """(rank, number of ranks) as the communicator itself reports them: RCCL's own view when it
