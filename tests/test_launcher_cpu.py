@@ -34,6 +34,9 @@ CHILD = textwrap.dedent("""
     s = comm.all_reduce([rank + 1.0, 10.0], "sum")
     m = comm.all_reduce([rank + 1.0, -rank], "max")
     comm.barrier()
+    g = comm.gather(np.arange(30) + 100.0 * rank)      # 3 x 30 values: more than one 64-value all-reduce
+    assert g.shape == (world, 30) and all(np.array_equal(g[k], np.arange(30) + 100.0 * k) for k in range(world))
+    assert comm.info() == (rank, world)
     comm.reduce_sum_image(0)
     if %r and rank == world - 1:
         sys.exit(3)
