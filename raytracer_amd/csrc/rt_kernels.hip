@@ -805,6 +805,13 @@ __device__ __forceinline__ void traverse_unified(const DevScene &sc, v3 O, v3 D,
                                                  LdsTop top) {
     Walk w;
     walk_begin<STATS>(w, st);
+    // Nothing of this lane's earlier vector-memory traffic may still be pending, in the compiler's
+    // books, when the loop is entered: it cannot see the hand-written loads of a step, so a load it
+    // believes outstanding from before the loop (a register it must not overwrite yet) makes it put
+    // a vmcnt(0) in front of the LDS arm's reads -- where, in a wavefront whose lanes split between
+    // the arms, it waits for the other lanes' global loads issued a moment earlier.  An explicit
+    // wait here (encoding: vmcnt(0), the other counters at their maxima) keeps those out of the loop.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     while (w.have) walk_step<STATS, STRIDE, LDS_DEPTH, TOP>(sc, O, D, ID, best, best_code, w, stack, spill, st, top);
 }
 
@@ -1201,6 +1208,7 @@ __device__ __forceinline__ void trace_body(const TraceParams &p) {
             } else {
                 int sp = 1;
                 stack[0] = 0u;
+                if (!FAST) __builtin_amdgcn_s_waitcnt(0x0F70);  // as in traverse_unified: no compiler-known load pending in the loop
                 while (sp > 0)
                     node_step<STATS, RT_TRACE_BLOCK, RT_STACK_LDS, TOP, FAST>(sc, ps.O, ps.D, ID, best, code, sp, stack, spill, st, top);
             }
