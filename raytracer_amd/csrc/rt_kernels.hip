@@ -573,35 +573,29 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
     // inner and visited: a node word other than kSkip
     const uint32_t in3 = (m3 - 0xC0000000u < 0x3FFFFFFFu) ? 1u : 0u, in2 = (m2 - 0xC0000000u < 0x3FFFFFFFu) ? 1u : 0u;
     const uint32_t in1 = (m1 - 0xC0000000u < 0x3FFFFFFFu) ? 1u : 0u, in0 = (m0 - 0xC0000000u < 0x3FFFFFFFu) ? 1u : 0u;
-    if (sp + 4 <= LDS_DEPTH) {
-        // all four candidate rows are in LDS: every child is stored at the running top and only
-        // an inner, visited child advances it, so a skipped child is overwritten by the next one
-        // or left above the final top; no branch, no predicate
-        uint32_t *w = stack + sp * STRIDE;
-        w[0] = m3 & 0x3FFFFFFFu;
-        w += in3 * STRIDE;
-        w[0] = m2 & 0x3FFFFFFFu;
-        w += in2 * STRIDE;
-        w[0] = m1 & 0x3FFFFFFFu;
-        w += in1 * STRIDE;
-        w[0] = m0 & 0x3FFFFFFFu;
-        sp += (int)(in3 + in2 + in1 + in0);
-    } else {
-#define PUSH_INNER(IN, META)                                                                      \
-    if (IN) {                                                                                     \
-        uint32_t idx = META & 0x3FFFFFFFu;                                                        \
-        if (sp < LDS_DEPTH) {                                                                     \
-            stack[sp * STRIDE] = idx;                                                             \
-            sp++;                                                                                 \
-        } else if (sp < LDS_DEPTH + RT_STACK_SPILL) {                                             \
-            spill[sp - LDS_DEPTH] = idx;                                                          \
-            sp++;                                                                                 \
-        } else {                                                                                  \
-            st.overflow++;                                                                        \
-        }                                                                                         \
+    {
+        // Rows the four children would take, in visiting order k = 3..0: every child is stored at the
+        // running top and only an inner, visited child advances it, so a skipped child is overwritten
+        // by the next one or left above the final top -- no branch on the child's kind.  A row at or
+        // beyond LDS_DEPTH is not in LDS: those stores are masked out here and redone into private
+        // memory below, which few lanes ever need (one pop in a hundred comes from that deep).
+        const int r3 = sp, r2 = r3 + (int)in3, r1 = r2 + (int)in2, r0 = r1 + (int)in1, top_after = r0 + (int)in0;
+        if (r3 < LDS_DEPTH) stack[r3 * STRIDE] = m3 & 0x3FFFFFFFu;
+        if (r2 < LDS_DEPTH) stack[r2 * STRIDE] = m2 & 0x3FFFFFFFu;
+        if (r1 < LDS_DEPTH) stack[r1 * STRIDE] = m1 & 0x3FFFFFFFu;
+        if (r0 < LDS_DEPTH) stack[r0 * STRIDE] = m0 & 0x3FFFFFFFu;
+        sp = top_after;
+        if (top_after > LDS_DEPTH) {
+            // a push onto a full stack is dropped and counted, and does not advance the top
+#define PUSH_DEEP(IN, META, ROW)                                                                  \
+    if (IN && ROW >= LDS_DEPTH) {                                                                 \
+        if (ROW < LDS_DEPTH + RT_STACK_SPILL) spill[ROW - LDS_DEPTH] = META & 0x3FFFFFFFu;        \
+        else st.overflow++;                                                                       \
     }
-        PUSH_INNER(in3, m3) PUSH_INNER(in2, m2) PUSH_INNER(in1, m1) PUSH_INNER(in0, m0)
-#undef PUSH_INNER
+            PUSH_DEEP(in3, m3, r3) PUSH_DEEP(in2, m2, r2) PUSH_DEEP(in1, m1, r1) PUSH_DEEP(in0, m0, r0)
+#undef PUSH_DEEP
+            sp = min(top_after, LDS_DEPTH + RT_STACK_SPILL);
+        }
     }
     // build the list by prepending in the order k = 0..3, so that k = 3 ends up in front
     uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
