@@ -491,18 +491,7 @@ def worker(args):
         out = run(args, r, comm, rank, world, name, bufs, build_s, rehearse)
         if out is not None:
             print(json.dumps(out), flush=True)
-        comm.barrier()
-        if rank == 0 and world > 1 and "RT_RDZV_DIR" not in os.environ:
-            # under an external launcher the rendezvous directory is this run's own: leave nothing behind
-            for f in list(comm.rdzv.dir.glob("*")) + list(comm.rdzv.dir.glob(".*")):
-                try:
-                    f.unlink()
-                except OSError:
-                    pass
-            try:
-                comm.rdzv.dir.rmdir()
-            except OSError:
-                pass
+        comm.finish()
     finally:
         r.close()
 

@@ -77,7 +77,7 @@ def _worker(args) -> int:
             if rank == 0:
                 r.finalize_sum(args.spp)
                 img = r.read_accumulation()
-            comm.barrier()
+            comm.finish()
         t_render = time.perf_counter() - t1
         if rank == 0:
             save_png(args.out, img)

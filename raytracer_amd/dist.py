@@ -264,6 +264,28 @@ class Comm:
     def barrier(self) -> None:
         self.all_reduce([1.0])
 
+    def finish(self) -> None:
+        """Last call of a run, on every rank: a barrier, and under an external launcher (no
+        RT_RDZV_DIR, so the directory is one this run derived and created) the rendezvous directory
+        is removed -- by rank 0, once every rank has said that it has read its last blob."""
+        self.barrier()
+        if self.world == 1 or os.environ.get("RT_RDZV_DIR"):
+            return   # spawn_ranks removes the directory it made
+        self.rdzv.publish(f"{self.tag}.done.r{self.rank}", b"1")
+        if self.rank != 0:
+            return
+        for k in range(self.world):
+            self.rdzv.wait(f"{self.tag}.done.r{k}")
+        for f in list(self.rdzv.dir.glob("*")) + list(self.rdzv.dir.glob(".*")):
+            try:
+                f.unlink()
+            except OSError:
+                pass
+        try:
+            self.rdzv.dir.rmdir()
+        except OSError:
+            pass
+
     def gather(self, values) -> np.ndarray:
         """(world, k) array of every rank's k float64 values, on every rank."""
         v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)

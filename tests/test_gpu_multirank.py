@@ -130,3 +130,31 @@ def test_bench_c5_rehearsal_with_four_ranks_tile_and_sample_shards():
     assert out["imbalance_max_over_mean"] >= 1.0 and out["stack_overflows"] == 0 and out["value"] > 0
     # every pixel-sample of the image was rendered exactly once across the ranks: rays of a 640x360 8-spp image
     assert 640 * 360 * 8 < out["value"] * 1e6 * out["ms_per_step"] * 1e-3 < 640 * 360 * 8 * 4.0
+
+
+def test_bench_under_torch_distributed_run_with_two_ranks():
+    """The external launcher: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...` (the ranks read RANK / LOCAL_RANK /
+    WORLD_SIZE from its environment and find each other through a directory derived from the
+    launcher's pid, start time, port and run id), the two ranks sharing this GPU with collectives
+    through host files."""
+    import json
+    import os
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RT_BENCH_REHEARSE="1")
+    env.pop("RT_RDZV_DIR", None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--width", "320", "--height", "184",
+                        "--detail", "0.05", "--sustain-seconds", "0", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert [r["rank"] for r in out["ranks"]] == [0, 1] and out["value"] > 0

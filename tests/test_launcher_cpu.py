@@ -115,6 +115,36 @@ def test_rendezvous_dir_of_an_external_launcher_is_private_and_per_run(tmp_path,
         tempfile.tempdir = None
 
 
+def test_ranks_of_an_external_launcher_find_each_other_and_leave_nothing_behind(tmp_path):
+    """Three ranks started the way an external launcher starts them (plain children of one process,
+    RANK / WORLD_SIZE / MASTER_PORT in the environment, no RT_RDZV_DIR): they meet in the derived
+    directory, rank 1 dawdles before its last barrier, and Comm.finish() removes the directory only
+    after every rank has read its last blob."""
+    code = textwrap.dedent("""
+        import os, sys, time
+        sys.path.insert(0, %r)
+        from raytracer_amd import dist as D
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        comm = D.Comm(None, rank, world, rehearse=True)
+        print(str(comm.rdzv.dir), flush=True)
+        assert comm.all_reduce([float(rank)], "sum")[0] == 3.0
+        assert comm.gather([rank * 2.0])[:, 0].tolist() == [0.0, 2.0, 4.0]
+        if rank == 1:
+            time.sleep(0.5)
+        comm.finish()
+    """ % str(ROOT))
+    env = dict(os.environ, WORLD_SIZE="3", MASTER_PORT="29533", TMPDIR=str(tmp_path), TORCHELASTIC_RUN_ID="t1",
+               TORCHELASTIC_RESTART_COUNT="0")
+    env.pop("RT_RDZV_DIR", None)
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK=str(k), LOCAL_RANK=str(k)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(3)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0, 0], [o[1][-800:] for o in outs]
+    dirs = {o[0].strip() for o in outs}
+    assert len(dirs) == 1 and Path(dirs.pop()).parent == tmp_path
+    assert list(tmp_path.iterdir()) == []
+
+
 def test_c4_line_carries_the_multi_gpu_diagnostics():
     """The JSON line of an 8-rank run, assembled from stand-in measurements (the GPU rehearsal of the
     same path is tests/test_gpu_multirank.py)."""
