@@ -383,9 +383,15 @@ __device__ __forceinline__ bool box_distance(v3 O, v3 D, v3 b0, v3 b1, float &t_
 // child boxes, sort, visit far to near (leaves are intersected at once, inner children pushed).
 // `stack` is this lane's column of the LDS stack (element stride STRIDE), `spill` its private
 // overflow array.  best/best_code: distance and metadata word of the best hit so far.
+// The leaves of the node visited last that are still to be intersected, in one of two forms.
+// As a list (the kernels with leaf steps of their own): v0.. are the pending leaves' words, v0 the
+// next one, pend their number -- the next word is at hand when a leaf step starts, before its loads.
+// As a mask (the unified step): v0..v3 are all four child words in visiting order (far to near) and
+// bit j of pend says that v_j is a leaf still to be intersected -- building it costs a third of the
+// instructions of the list, and the unified step picks its next item at the end of a step anyway.
 struct LeafList {
-    uint32_t l0, l1, l2, l3;  // metadata words of the pending leaves, l0 is tested first
-    int n;
+    uint32_t v0, v1, v2, v3;
+    uint32_t pend;
 };
 
 // Raw words of one node as loaded, before any arithmetic: the loads can be issued early and
@@ -506,7 +512,7 @@ __device__ __forceinline__ void node_fetch(const DevScene &sc, int &sp, const ui
 // Slab tests, sort, pushes and leaf list for a fetched node.  FAST: the child boxes come from 8-bit
 // codes, plane distance = fma(code, scale * ID, (origin - O) * ID) with ID kept finite by the
 // caller, the exit distance is widened by 4 ulp, and an empty child slot (0xFFFFFFFF) is never valid.
-template <bool STATS, int STRIDE, int LDS_DEPTH, bool FAST = false>
+template <bool STATS, int STRIDE, int LDS_DEPTH, bool FAST = false, bool MASK = false>
 __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd, v3 O, v3 ID, float best, int &sp,
                                           uint32_t *stack, uint32_t *spill, LeafList &ll, LaneStats &st) {
     uint32_t m0 = f2u(nd.mt.x), m1 = f2u(nd.mt.y), m2 = f2u(nd.mt.z), m3 = f2u(nd.mt.w);
@@ -597,13 +603,20 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
             sp = min(top_after, LDS_DEPTH + RT_STACK_SPILL);
         }
     }
+    // the leaves among the visited children (a word below 0xC0000000), k = 3 first
+    if (MASK) {
+        // the words stay where the sort left them, one bit per word marks the leaves
+        ll.v0 = m3, ll.v1 = m2, ll.v2 = m1, ll.v3 = m0;
+        ll.pend = (m3 < 0xC0000000u ? 1u : 0u) | (m2 < 0xC0000000u ? 2u : 0u) | (m1 < 0xC0000000u ? 4u : 0u) |
+                  (m0 < 0xC0000000u ? 8u : 0u);
+        return;
+    }
     // build the list by prepending in the order k = 0..3, so that k = 3 ends up in front
-    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
-    int nl = 0;
+    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, nl = 0;
 #define ADD_LEAF(META)                                                                            \
     {                                                                                             \
-        bool lf = META < 0xC0000000u; /* a visited leaf */                                        \
-        nl += lf ? 1 : 0;                                                                         \
+        bool lf = META < 0xC0000000u;                                                             \
+        nl += lf ? 1u : 0u;                                                                       \
         l3 = lf ? l2 : l3;                                                                        \
         l2 = lf ? l1 : l2;                                                                        \
         l1 = lf ? l0 : l1;                                                                        \
@@ -611,11 +624,8 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
     }
     ADD_LEAF(m0) ADD_LEAF(m1) ADD_LEAF(m2) ADD_LEAF(m3)
 #undef ADD_LEAF
-    ll.l0 = l0;
-    ll.l1 = l1;
-    ll.l2 = l2;
-    ll.l3 = l3;
-    ll.n = nl;
+    ll.v0 = l0, ll.v1 = l1, ll.v2 = l2, ll.v3 = l3;
+    ll.pend = nl;
 }
 
 template <bool STATS, int STRIDE, int LDS_DEPTH, int TOP = 0, bool FAST = false>
@@ -630,11 +640,11 @@ __device__ __forceinline__ void node_part(const DevScene &sc, v3 O, v3 ID, float
 template <bool STATS>
 __device__ __forceinline__ void leaf_one(const DevScene &sc, v3 O, v3 D, float &best, uint32_t &best_code,
                                          LeafList &ll, LaneStats &st) {
-    uint32_t meta = ll.l0;
-    ll.l0 = ll.l1;
-    ll.l1 = ll.l2;
-    ll.l2 = ll.l3;
-    ll.n--;
+    uint32_t meta = ll.v0;  // list form
+    ll.v0 = ll.v1;
+    ll.v1 = ll.v2;
+    ll.v2 = ll.v3;
+    ll.pend--;
     uint32_t type = meta >> 30, idx = meta & 0x3FFFFFFFu;
     float t;
     bool hit;
@@ -665,7 +675,7 @@ __device__ __forceinline__ void node_step(const DevScene &sc, v3 O, v3 D, v3 ID,
                                           LdsTop top = nullptr) {
     LeafList ll;
     node_part<STATS, STRIDE, LDS_DEPTH, TOP, FAST>(sc, O, ID, best, sp, stack, spill, ll, st, top);
-    while (ll.n > 0) leaf_one<STATS>(sc, O, D, best, best_code, ll, st);
+    while (ll.pend != 0u) leaf_one<STATS>(sc, O, D, best, best_code, ll, st);
 }
 
 // The whole traversal of one ray (compute.glsl:225-330) with ONE kind of step for nodes and
@@ -692,7 +702,7 @@ struct Walk {
 template <bool STATS>
 __device__ __forceinline__ void walk_begin(Walk &w, LaneStats &st) {
     w.cur = 0xC0000000u;  // the root node
-    w.ll = {0u, 0u, 0u, 0u, 0};
+    w.ll = {0u, 0u, 0u, 0u, 0u};
     w.sp = 0;
     w.have = true;
     if (STATS) st.max_sp = max(st.max_sp, 1u);  // the reference pushes the root before its loop
@@ -726,14 +736,22 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
             else if (type == 0u) rec = (uintptr_t)(sc.tris + (size_t)min(idx, sc.n_tris) * kTriVec);
             else if (type == 1u) rec = (uintptr_t)(sc.spheres + (size_t)min(idx, sc.n_spheres) * kSphereVec);
             else rec = (uintptr_t)(sc.boxes + (size_t)min(idx, sc.n_boxes) * 2);
-            const float4 *line = reinterpret_cast<const float4 *>(rec & ~(uintptr_t)127);
+            // Seven loads cover the first 112 bytes of the record's 128-byte line, except for a
+            // triangle: its first three start at the record itself, so that its 48 bytes arrive in
+            // a0..a2 whichever half of the line it lies in, and the other four, which its lane does not
+            // use, re-read the start of the line -- no second line is touched, nothing is read beyond
+            // a buffer.  (Only the low address word differs: records do not straddle lines.)
+            const uint32_t lo = (uint32_t)rec, line_lo = lo & ~127u;
+            const uintptr_t hi = rec & ~(uintptr_t)0xFFFFFFFFu;
+            const uintptr_t first = hi | (type == 0u ? lo : line_lo);
+            const uintptr_t rest = hi | (type == 0u ? line_lo : line_lo + 48u);
             asm volatile(
                 "global_load_dwordx4 %0, %7, off\n\tglobal_load_dwordx4 %1, %7, off offset:16\n\t"
-                "global_load_dwordx4 %2, %7, off offset:32\n\tglobal_load_dwordx4 %3, %7, off offset:48\n\t"
-                "global_load_dwordx4 %4, %7, off offset:64\n\tglobal_load_dwordx4 %5, %7, off offset:80\n\t"
-                "global_load_dwordx4 %6, %7, off offset:96"
+                "global_load_dwordx4 %2, %7, off offset:32\n\tglobal_load_dwordx4 %3, %8, off\n\t"
+                "global_load_dwordx4 %4, %8, off offset:16\n\tglobal_load_dwordx4 %5, %8, off offset:32\n\t"
+                "global_load_dwordx4 %6, %8, off offset:48"
                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6)
-                : "v"(line)
+                : "v"(first), "v"(rest)
                 : "memory");
         }
         // either kind returns in order: vector k has arrived when at most 6 - k of its kind are outstanding
@@ -749,14 +767,13 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
             if (STATS) st.nodes++;
             NodeRegs nd;
             nd.lox = F4(a0), nd.hix = F4(a1), nd.loy = F4(a2), nd.hiy = F4(a3), nd.loz = F4(a4), nd.hiz = F4(a5), nd.mt = F4(a6);
-            node_test<STATS, STRIDE, LDS_DEPTH, false>(sc, nd, O, ID, best, sp, stack, spill, ll, st);
+            node_test<STATS, STRIDE, LDS_DEPTH, false, true>(sc, nd, O, ID, best, sp, stack, spill, ll, st);
         } else {
             float t;
             bool hit;
             if (type == 0u) {
-                const bool upper = (rec & 64u) != 0u;  // second record of its line
                 if (STATS) st.tri++;
-                hit = tri_distance(O, D, upper ? F4(a4) : F4(a0), upper ? F4(a5) : F4(a1), upper ? F4(a6) : F4(a2), t);
+                hit = tri_distance(O, D, F4(a0), F4(a1), F4(a2), t);
             } else if (type == 1u) {
                 const uint32_t q = (uint32_t)(rec >> 5) & 3u;  // which of the four records of its line
                 const vec4f s0 = q == 0u ? a0 : q == 1u ? a2 : q == 2u ? a4 : a6;
@@ -777,18 +794,18 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
         // the next item: the nearest pending leaf of the node just visited, else the next node
         // (written with selects and one converging branch: the loop must keep a single back edge, or
         // the compiler nests it and the lanes at a leaf hold up the lanes at a node again)
-        const bool from_list = ll.n > 0;
+        const bool from_list = ll.pend != 0u;
         const bool from_stack = !from_list && sp > 0;
         uint32_t popped = 0u;
         if (from_stack) {
             if (STATS) st.max_sp = max(st.max_sp, (uint32_t)sp);
             popped = 0xC0000000u | stack_pop<STRIDE, LDS_DEPTH>(sp, stack, spill);
         }
-        cur = from_list ? ll.l0 : popped;
-        ll.l0 = from_list ? ll.l1 : ll.l0;
-        ll.l1 = from_list ? ll.l2 : ll.l1;
-        ll.l2 = from_list ? ll.l3 : ll.l2;
-        ll.n -= from_list ? 1 : 0;
+        // (with pend == 0 the selection below yields v3 and leaves pend at 0)
+        const int j = __builtin_ctz(ll.pend | 8u);
+        const uint32_t leaf = j == 0 ? ll.v0 : j == 1 ? ll.v1 : j == 2 ? ll.v2 : ll.v3;
+        ll.pend &= ll.pend - 1u;
+        cur = from_list ? leaf : popped;
         have = from_list || from_stack;
     }
 }
@@ -1404,8 +1421,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_regroup_kernel(T
                 const uint32_t m = mover_base + below;
                 xfer[4 * m] = make_float4(O.x, O.y, O.z, best);
                 xfer[4 * m + 1] = make_float4(D.x, D.y, D.z, u2f(code));
-                xfer[4 * m + 2] = make_float4(u2f(w.cur), u2f(w.ll.l0), u2f(w.ll.l1), u2f(w.ll.l2));
-                xfer[4 * m + 3] = make_float4(u2f(w.ll.l3), u2f((uint32_t)w.ll.n), u2f((uint32_t)w.sp), u2f(slot));
+                xfer[4 * m + 2] = make_float4(u2f(w.cur), u2f(w.ll.v0), u2f(w.ll.v1), u2f(w.ll.v2));
+                xfer[4 * m + 3] = make_float4(u2f(w.ll.v3), u2f(w.ll.pend), u2f((uint32_t)w.sp), u2f(slot));
                 if (STATS) xvisits[m] = visits;
                 has = false;
                 w.have = false;
@@ -1418,8 +1435,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_regroup_kernel(T
                     O = V(a.x, a.y, a.z), D = V(b.x, b.y, b.z);
                     ID = V(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
                     best = a.w, code = f2u(b.w);
-                    w.cur = f2u(c2.x), w.ll.l0 = f2u(c2.y), w.ll.l1 = f2u(c2.z), w.ll.l2 = f2u(c2.w);
-                    w.ll.l3 = f2u(d2.x), w.ll.n = (int)f2u(d2.y), w.sp = (int)f2u(d2.z), slot = f2u(d2.w);
+                    w.cur = f2u(c2.x), w.ll.v0 = f2u(c2.y), w.ll.v1 = f2u(c2.z), w.ll.v2 = f2u(c2.w);
+                    w.ll.v3 = f2u(d2.x), w.ll.pend = f2u(d2.y), w.sp = (int)f2u(d2.z), slot = f2u(d2.w);
                     w.have = true;
                     if (STATS) visits = xvisits[h];
                     has = true;
