@@ -207,9 +207,15 @@ int rt_set_traversal_variant(rt_ctx *ctx, int variant);
  * ("0000:05:00.0"; `pci_bus_id` must hold at least 16 bytes).
  * rt_shader_clock: the shader clock in GHz the megakernel's wavefronts ran at since the last
  * rt_reset_stats, measured by the kernel itself (a few wavefronts per launch compare the shader
- * cycle counter with the constant 100 MHz counter over their lifetime); 0 if nothing was sampled. */
+ * cycle counter with the constant 100 MHz counter over their lifetime); 0 if nothing was sampled.
+ * rt_selftest: checks on the device the one place where the kernels replace an IEEE operation of
+ * the reference by a shorter sequence claimed to give the same bits: the reciprocal of the triangle
+ * test's determinant (compute.glsl:887, `1.0 / det`).  Runs over every float (about 0.1 s) and
+ * returns the number of values for which the two differ; anything but 0 means this GPU must not
+ * be trusted to reproduce the reference. */
 int rt_device_info(rt_ctx *ctx, int *device, char *pci_bus_id, size_t pci_bus_id_bytes);
 int rt_shader_clock(rt_ctx *ctx, double *ghz);
+int rt_selftest(rt_ctx *ctx, unsigned long long *reciprocal_mismatches);
 
 /*
  * Collectives for multi-GPU runs: one process per GPU, RCCL over xGMI, no framework needed (no

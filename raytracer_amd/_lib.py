@@ -22,7 +22,7 @@ SYMBOLS = (
     "rt_finalize_sum", "rt_render_noalloc", "rt_comm_unique_id", "rt_comm_init", "rt_comm_reduce_sum",
     "rt_comm_all_reduce_f64", "rt_comm_barrier", "rt_set_fast_mode", "rt_fast_bvh_size", "rt_fast_bvh_export",
     "rt_traversal_variant",
-    "rt_map_image", "rt_set_rendered_frames", "rt_set_traversal_variant", "rt_device_info", "rt_shader_clock",
+    "rt_map_image", "rt_set_rendered_frames", "rt_set_traversal_variant", "rt_device_info", "rt_shader_clock", "rt_selftest",
     "rt_comm_info",
 )
 RT_COMM_ID_BYTES = 128
@@ -101,6 +101,7 @@ def load():
         "rt_set_traversal_variant": [vp, C.c_int],
         "rt_device_info": [vp, C.POINTER(C.c_int), C.c_char_p, C.c_size_t],
         "rt_shader_clock": [vp, C.POINTER(C.c_double)],
+        "rt_selftest": [vp, C.POINTER(C.c_ulonglong)],
         "rt_render_noalloc": [C.c_int, C.POINTER(RtSceneView), C.c_int, C.c_int, C.c_uint32, C.c_float, vp, vp,
                               C.c_uint32, vp],
     }

@@ -1085,6 +1085,24 @@ int rt_shader_clock(rt_ctx *c, double *ghz) {
     return 0;
 }
 
+int rt_selftest(rt_ctx *c, unsigned long long *reciprocal_mismatches) {
+    if (!c || !reciprocal_mismatches) return fail("rt_selftest: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = join(c)) return rc;
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof *d));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof *d, c->stream);
+    if (e == hipSuccess) {
+        rt::launch_reciprocal_selftest(d, c->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(reciprocal_mismatches, d, sizeof *d, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(std::string("rt_selftest: ") + hipGetErrorString(e));
+    return 0;
+}
+
 int rt_sum_buffer(rt_ctx *c, float **device_ptr, size_t *nbytes) {
     if (!c || !device_ptr || !nbytes) return fail("rt_sum_buffer: null argument");
     *device_ptr = reinterpret_cast<float *>(c->sum);

@@ -104,6 +104,7 @@ void launch_trace_fast(const TraceParams &p, int mode, bool aux, bool stats, hip
 void launch_trace_regroup(const TraceParams &p, int mode, bool aux, bool stats, hipStream_t s);
 
 // repack kernels: reference byte layouts -> device records (n elements + 1 zero-source sentinel)
+void launch_reciprocal_selftest(unsigned long long *mismatches, hipStream_t s);
 void launch_repack_nodes(const uint32_t *src, uint32_t n, const float smin[3], const float sext[3],
                          const uint32_t *order, const uint32_t *rank, float4 *dst, hipStream_t s);
 void launch_repack_tris(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s);

@@ -316,12 +316,42 @@ struct LaneStats {
 };
 
 // compute.glsl:875-919 up to the distance; normal and position are derived after traversal
+// 1.0f / x, correctly rounded.  For 1e-6 <= |x| <= 1e30 the hardware's reciprocal estimate with one
+// refinement step, fma(fma(-x, r, 1), r, r), IS the correctly rounded quotient -- checked over every
+// float in that range on the device itself (reciprocal_selftest_kernel below, rt_selftest in the
+// ABI) -- and costs 3 instructions instead of the 10 of the general division, which anything outside
+// the range (infinities and NaNs included) still takes.
+__device__ __forceinline__ float reciprocal(float x) {
+#ifndef RT_GENERAL_DIVISION  // (A/B builds)
+    if (__builtin_expect(fabsf(x) <= 1e30f && fabsf(x) >= 1e-6f, 1)) {
+        const float r = __builtin_amdgcn_rcpf(x);
+        return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+    }
+#endif
+    return 1.0f / x;
+}
+
+// Counts the floats for which reciprocal() differs from the division, over all 2^32 bit patterns.
+__global__ void reciprocal_selftest_kernel(unsigned long long *mismatches) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (uint64_t u = tid; u < (1ull << 32); u += stride) {
+        const float x = u2f((uint32_t)u);
+        const float want = 1.0f / x, got = reciprocal(x);
+        if (f2u(want) != f2u(got) && !(want != want && got != got)) bad++;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+void launch_reciprocal_selftest(unsigned long long *mismatches, hipStream_t s) {
+    hipLaunchKernelGGL(reciprocal_selftest_kernel, dim3(4096), dim3(256), 0, s, mismatches);
+}
+
 __device__ __forceinline__ bool tri_distance(v3 O, v3 D, float4 r0, float4 r1, float4 r2, float &t_out) {
     v3 v0 = V(r0.x, r0.y, r0.z), e1 = V(r1.x, r1.y, r1.z), e2 = V(r2.x, r2.y, r2.z);
     v3 p = cross(D, e2);
     float det = dot(e1, p);
     if (fabsf(det) < 1e-6f) return false;
-    float inv = 1.0f / det;
+    float inv = reciprocal(det);
     v3 tv = O - v0;
     float u = dot(tv, p) * inv;
     if (u < 0.0f || u > 1.0f) return false;
@@ -486,7 +516,7 @@ __device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeR
     nd.hiz = ld4(np + 5), nd.mt = ld4(np + 6);
 }
 
-// Pops the node index on top of the stack.
+// Pops the word on top of the stack (entries are child words as the nodes hold them: 3 << 30 | node index).
 template <int STRIDE, int LDS_DEPTH>
 __device__ __forceinline__ uint32_t stack_pop(int &sp, const uint32_t *stack, const uint32_t *spill) {
     --sp;
@@ -506,7 +536,7 @@ __device__ __forceinline__ void node_fetch(const DevScene &sc, int &sp, const ui
         st.max_sp = max(st.max_sp, (uint32_t)sp);
         st.nodes++;
     }
-    node_load<TOP, FAST>(sc, stack_pop<STRIDE, LDS_DEPTH>(sp, stack, spill), nd, top);
+    node_load<TOP, FAST>(sc, stack_pop<STRIDE, LDS_DEPTH>(sp, stack, spill) & 0x3FFFFFFFu, nd, top);
 }
 
 // Slab tests, sort, pushes and leaf list for a fetched node.  FAST: the child boxes come from 8-bit
@@ -586,16 +616,16 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
         // beyond LDS_DEPTH is not in LDS: those stores are masked out here and redone into private
         // memory below, which few lanes ever need (one pop in a hundred comes from that deep).
         const int r3 = sp, r2 = r3 + (int)in3, r1 = r2 + (int)in2, r0 = r1 + (int)in1, top_after = r0 + (int)in0;
-        if (r3 < LDS_DEPTH) stack[r3 * STRIDE] = m3 & 0x3FFFFFFFu;
-        if (r2 < LDS_DEPTH) stack[r2 * STRIDE] = m2 & 0x3FFFFFFFu;
-        if (r1 < LDS_DEPTH) stack[r1 * STRIDE] = m1 & 0x3FFFFFFFu;
-        if (r0 < LDS_DEPTH) stack[r0 * STRIDE] = m0 & 0x3FFFFFFFu;
+        if (r3 < LDS_DEPTH) stack[r3 * STRIDE] = m3;
+        if (r2 < LDS_DEPTH) stack[r2 * STRIDE] = m2;
+        if (r1 < LDS_DEPTH) stack[r1 * STRIDE] = m1;
+        if (r0 < LDS_DEPTH) stack[r0 * STRIDE] = m0;
         sp = top_after;
         if (top_after > LDS_DEPTH) {
             // a push onto a full stack is dropped and counted, and does not advance the top
 #define PUSH_DEEP(IN, META, ROW)                                                                  \
     if (IN && ROW >= LDS_DEPTH) {                                                                 \
-        if (ROW < LDS_DEPTH + RT_STACK_SPILL) spill[ROW - LDS_DEPTH] = META & 0x3FFFFFFFu;        \
+        if (ROW < LDS_DEPTH + RT_STACK_SPILL) spill[ROW - LDS_DEPTH] = META;                      \
         else st.overflow++;                                                                       \
     }
             PUSH_DEEP(in3, m3, r3) PUSH_DEEP(in2, m2, r2) PUSH_DEEP(in1, m1, r1) PUSH_DEEP(in0, m0, r0)
@@ -718,7 +748,7 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
     bool &have = w.have;
     {
         const uint32_t type = cur >> 30, idx = cur & 0x3FFFFFFFu;
-        const uint32_t ni = min(idx, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
+        const uint32_t ni = idx;  // never beyond the sentinel: the repack has clamped every child word that names a node
         const bool in_lds = type == 3u && ni < (uint32_t)TOP;
         vec4f a0, a1, a2, a3, a4, a5, a6;  // in flight until the waits below: see node_load and tools/check_isa.py
         uintptr_t rec = 0;  // address of the item's record
@@ -799,7 +829,7 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
         uint32_t popped = 0u;
         if (from_stack) {
             if (STATS) st.max_sp = max(st.max_sp, (uint32_t)sp);
-            popped = 0xC0000000u | stack_pop<STRIDE, LDS_DEPTH>(sp, stack, spill);
+            popped = stack_pop<STRIDE, LDS_DEPTH>(sp, stack, spill);
         }
         // (with pend == 0 the selection below yields v3 and leaves pend at 0)
         const int j = __builtin_ctz(ll.pend | 8u);

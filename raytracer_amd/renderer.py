@@ -191,6 +191,13 @@ class Renderer:
         _lib.check(self._L.rt_shader_clock(self._ctx, C.byref(g)))
         return g.value
 
+    def selftest(self) -> int:
+        """Number of floats for which the kernels' short reciprocal differs from the division it
+        stands for, checked on the device over every float; must be 0."""
+        n = C.c_ulonglong()
+        _lib.check(self._L.rt_selftest(self._ctx, C.byref(n)))
+        return int(n.value)
+
     def fast_bvh(self) -> np.ndarray:
         """The fast-mode tree as built for the current scene: (n + 1, 16) uint32, the last node a sentinel."""
         nn = C.c_uint32()

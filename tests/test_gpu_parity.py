@@ -847,3 +847,10 @@ def test_experiment_knobs_change_no_pixel(knobs):
             assert np.array_equal(code, aux[..., 0]) and np.array_equal(tbits, aux[..., 1])
     finally:
         r.close()
+
+
+def test_the_short_reciprocal_equals_the_division_for_every_float(renderer):
+    """The triangle test's 1 / det is computed as the hardware estimate plus one refinement step where
+    that is the correctly rounded quotient (1e-6 <= |det| <= 1e30) and by the general division
+    elsewhere: the device compares the two over all 2^32 bit patterns."""
+    assert renderer.selftest() == 0
