@@ -32,8 +32,9 @@ struct RawBuffer {           // device copy of an uploaded reference-layout buff
     uint32_t *raw = nullptr;  // as uploaded
     size_t raw_bytes = 0;
     uint32_t count = 0;       // elements
-    float4 *packed = nullptr; // device records (count + 1 elements)
-    size_t packed_cap = 0;    // capacity in float4
+    float4 *packed = nullptr; // device records (count + 1 elements); for nodes, triangles, spheres and
+                              // boxes a region of the context's record arena, an allocation of its own otherwise
+    size_t packed_cap = 0;    // capacity in float4 (allocations of their own)
     bool dirty = true;        // packed is stale
 };
 
@@ -127,6 +128,11 @@ struct rt_ctx {
     RawBuffer spheres, planes, boxes, mats, nodes, tris;
     uint32_t *node_order = nullptr, *node_rank = nullptr;  // device: breadth-first renumbering of the nodes
     size_t node_perm_cap = 0;
+    // Nodes, triangles, spheres and boxes -- every record a traversal step may fetch -- in one
+    // allocation, in this order, each region beginning on a 128-byte line (DevScene in rt_internal.h).
+    float4 *arena = nullptr;
+    size_t arena_cap = 0;            // float4
+    rt::LeafRegions leaves = {0, 0, 0, 0, 0, 0};
     std::vector<uint32_t> host_nodes;                       // host copy of the uploaded node words (for the renumbering)
     float smin[3] = {0, 0, 0}, sext[3] = {0, 0, 0};
     float inv_vp[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -350,13 +356,12 @@ int trace_stream(rt_ctx *c, int b, bool serial, hipStream_t *out) {
     return 0;
 }
 
-// brings the device records of one binding up to date
+// brings the device records of one binding with an allocation of its own (planes, materials) up to date
 int repack(rt_ctx *c, int binding) {
     RawBuffer *b = buffer_of(c, binding);
     if (!b->dirty) return 0;
     if (int rc = sync_all(c)) return rc;  // frames in flight still read the old records
     c->main_dirty = true;
-    // + 8: the traversal fetches records by the 128-byte line, so the line of the last record must be readable
     size_t need = ((size_t)b->count + 1) * vecs_per_elem(binding) + 8;
     if (need > b->packed_cap) {
         float4 *old = b->packed;
@@ -365,35 +370,68 @@ int repack(rt_ctx *c, int binding) {
         HIP_TRY(hipMalloc((void **)&b->packed, need * sizeof(float4)));
         b->packed_cap = need;
     }
-    switch (binding) {
-        case RT_BINDING_BVH: {
-            std::vector<uint32_t> order, rank;
-            node_order(c->host_nodes.data(), b->count, rt::kLdsTopNodes, c->node_layout, order, rank);
-            if ((size_t)b->count + 1 > c->node_perm_cap) {
-                uint32_t *old_order = c->node_order, *old_rank = c->node_rank;
-                c->node_order = c->node_rank = nullptr, c->node_perm_cap = 0;
-                if (old_order) HIP_TRY(hipFree(old_order));
-                if (old_rank) HIP_TRY(hipFree(old_rank));
-                HIP_TRY(hipMalloc((void **)&c->node_order, ((size_t)b->count + 1) * sizeof(uint32_t)));
-                HIP_TRY(hipMalloc((void **)&c->node_rank, ((size_t)b->count + 1) * sizeof(uint32_t)));
-                c->node_perm_cap = (size_t)b->count + 1;
-            }
-            if (b->count) {
-                HIP_TRY(hipMemcpyAsync(c->node_order, order.data(), (size_t)b->count * 4, hipMemcpyHostToDevice, c->stream));
-                HIP_TRY(hipMemcpyAsync(c->node_rank, rank.data(), (size_t)b->count * 4, hipMemcpyHostToDevice, c->stream));
-                // the vectors die at the end of this block: the copies must have read them by then
-                HIP_TRY(hipStreamSynchronize(c->stream));
-            }
-            rt::launch_repack_nodes(b->raw, b->count, c->smin, c->sext, c->node_order, c->node_rank, b->packed, c->stream);
-            break;
-        }
-        case RT_BINDING_TRIANGLES: rt::launch_repack_tris(b->raw, b->count, b->packed, c->stream); break;
-        case RT_BINDING_SPHERES: rt::launch_repack_spheres(b->raw, b->count, b->packed, c->stream); break;
-        case RT_BINDING_MATERIALS: rt::launch_repack_mats(b->raw, b->count, b->packed, c->stream); break;
-        default: rt::launch_copy_raw32(b->raw, b->count, b->packed, c->stream); break;
-    }
+    if (binding == RT_BINDING_MATERIALS) rt::launch_repack_mats(b->raw, b->count, b->packed, c->stream);
+    else rt::launch_copy_raw32(b->raw, b->count, b->packed, c->stream);
     HIP_TRY(hipGetLastError());
     b->dirty = false;
+    return 0;
+}
+
+// Brings the record arena up to date: if any of its four bindings changed, the regions are laid out
+// anew and all four are repacked -- the child words of the node records name records by position, so
+// they depend on where every region begins and on how many records it holds.
+int repack_arena(rt_ctx *c) {
+    RawBuffer *part[4] = {&c->nodes, &c->tris, &c->spheres, &c->boxes};
+    const int vecs[4] = {rt::kNodeVec, rt::kTriVec, rt::kSphereVec, 2};
+    if (!(part[0]->dirty || part[1]->dirty || part[2]->dirty || part[3]->dirty)) return 0;
+    if (int rc = sync_all(c)) return rc;  // frames in flight still read the old records
+    c->main_dirty = true;
+    size_t begin[4], total = 0;
+    for (int k = 0; k < 4; k++) {
+        begin[k] = total;
+        // count + 1 records (the closing all-zero one), rounded up to whole 128-byte lines: the traversal
+        // fetches records by the line, so the line of the last record must be readable
+        total += (((size_t)part[k]->count + 1) * vecs[k] + 7) / 8 * 8;
+    }
+    if (total / 2 >= (1u << 30)) return fail("the scene's records exceed 32 GB: positions no longer fit a child word");
+    if (total > c->arena_cap) {
+        float4 *old = c->arena;
+        c->arena = nullptr, c->arena_cap = 0;
+        for (RawBuffer *b : part) b->packed = nullptr, b->dirty = true;  // a failure below leaves "no records"
+        if (old) HIP_TRY(hipFree(old));
+        HIP_TRY(hipMalloc((void **)&c->arena, total * sizeof(float4)));
+        c->arena_cap = total;
+    }
+    for (int k = 0; k < 4; k++) part[k]->packed = c->arena + begin[k], part[k]->dirty = true;
+    c->leaves = {(uint32_t)(begin[1] / 2), (uint32_t)(begin[2] / 2), (uint32_t)(begin[3] / 2),
+                 c->tris.count, c->spheres.count, c->boxes.count};
+    {
+        RawBuffer *b = &c->nodes;
+        std::vector<uint32_t> order, rank;
+        node_order(c->host_nodes.data(), b->count, rt::kLdsTopNodes, c->node_layout, order, rank);
+        if ((size_t)b->count + 1 > c->node_perm_cap) {
+            uint32_t *old_order = c->node_order, *old_rank = c->node_rank;
+            c->node_order = c->node_rank = nullptr, c->node_perm_cap = 0;
+            if (old_order) HIP_TRY(hipFree(old_order));
+            if (old_rank) HIP_TRY(hipFree(old_rank));
+            HIP_TRY(hipMalloc((void **)&c->node_order, ((size_t)b->count + 1) * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void **)&c->node_rank, ((size_t)b->count + 1) * sizeof(uint32_t)));
+            c->node_perm_cap = (size_t)b->count + 1;
+        }
+        if (b->count) {
+            HIP_TRY(hipMemcpyAsync(c->node_order, order.data(), (size_t)b->count * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->node_rank, rank.data(), (size_t)b->count * 4, hipMemcpyHostToDevice, c->stream));
+            // the vectors die at the end of this block: the copies must have read them by then
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        rt::launch_repack_nodes(b->raw, b->count, c->smin, c->sext, c->node_order, c->node_rank, c->leaves, b->packed,
+                                c->stream);
+    }
+    rt::launch_repack_tris(c->tris.raw, c->tris.count, c->tris.packed, c->stream);
+    rt::launch_repack_spheres(c->spheres.raw, c->spheres.count, c->spheres.packed, c->stream);
+    rt::launch_copy_raw32(c->boxes.raw, c->boxes.count, c->boxes.packed, c->stream);
+    HIP_TRY(hipGetLastError());
+    for (RawBuffer *b : part) b->dirty = false;
     return 0;
 }
 
@@ -423,8 +461,8 @@ int prepare_fast(rt_ctx *c) {
 }
 
 int prepare_scene(rt_ctx *c, rt::DevScene *s) {
-    for (int binding : {RT_BINDING_SPHERES, RT_BINDING_PLANES, RT_BINDING_BOXES, RT_BINDING_MATERIALS,
-                        RT_BINDING_BVH, RT_BINDING_TRIANGLES})
+    if (int rc = repack_arena(c)) return rc;
+    for (int binding : {RT_BINDING_PLANES, RT_BINDING_MATERIALS})
         if (int rc = repack(c, binding)) return rc;
     s->nodes = c->nodes.packed;
     s->tris = c->tris.packed;
@@ -438,6 +476,7 @@ int prepare_scene(rt_ctx *c, rt::DevScene *s) {
     s->n_boxes = c->boxes.count;
     s->n_planes = c->planes.count;
     s->n_mats = c->mats.count;
+    s->unit_tris = c->leaves.unit_tris, s->unit_spheres = c->leaves.unit_spheres, s->unit_boxes = c->leaves.unit_boxes;
     s->fnodes = nullptr;
     s->n_fnodes = 0;
     if (c->fast) {
@@ -695,10 +734,11 @@ int rt_destroy(rt_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     rt::comm_destroy(c->comm);
     if (c->comm_scratch) (void)hipFree(c->comm_scratch);
-    for (RawBuffer *b : {&c->spheres, &c->planes, &c->boxes, &c->mats, &c->nodes, &c->tris}) {
+    for (RawBuffer *b : {&c->spheres, &c->planes, &c->boxes, &c->mats, &c->nodes, &c->tris})
         if (b->raw) (void)hipFree(b->raw);
+    for (RawBuffer *b : {&c->planes, &c->mats})
         if (b->packed) (void)hipFree(b->packed);
-    }
+    if (c->arena) (void)hipFree(c->arena);
     if (c->fnodes) (void)hipFree(c->fnodes);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (void *p : {(void *)c->lpt_cost[0], (void *)c->lpt_cost[1], (void *)c->lpt_order[0], (void *)c->lpt_order[1]})

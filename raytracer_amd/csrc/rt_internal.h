@@ -36,6 +36,11 @@ constexpr int kSphereVec = 2;
 constexpr int kMatVec = 4;
 
 struct DevScene {
+    // nodes, tris, spheres and boxes are regions of ONE allocation that begins with the nodes, and a
+    // child word in a device node record names its record by position: type << 30 | offset from
+    // `nodes` in units of 32 bytes (unit_* = where the regions begin).  A traversal step thus forms
+    // any record's address with one shift-and-add, whatever the kind; reference_word() in
+    // rt_kernels.hip turns such a word back into the reference's type << 30 | index.
     const float4 *nodes;
     const float4 *tris;
     const float4 *spheres;
@@ -45,6 +50,7 @@ struct DevScene {
     // element counts; every repacked array carries one extra all-zero-source element at index n,
     // which is what an out-of-range index reads (GL robust buffer access returns zeros)
     uint32_t n_nodes, n_tris, n_spheres, n_boxes, n_planes, n_mats;
+    uint32_t unit_tris, unit_spheres, unit_boxes;
     // fast mode only (rt_fastbvh.cpp): the library's own tree, 4 x float4 per node, n_fnodes nodes + a sentinel
     const float4 *fnodes;
     uint32_t n_fnodes;
@@ -105,8 +111,15 @@ void launch_trace_regroup(const TraceParams &p, int mode, bool aux, bool stats, 
 
 // repack kernels: reference byte layouts -> device records (n elements + 1 zero-source sentinel)
 void launch_reciprocal_selftest(unsigned long long *mismatches, hipStream_t s);
+// Where the leaf records lie relative to the node records (units of 32 bytes) and how many there are:
+// the node repack turns every child word into type << 30 | position (see DevScene).
+struct LeafRegions {
+    uint32_t unit_tris, unit_spheres, unit_boxes;
+    uint32_t n_tris, n_spheres, n_boxes;
+};
 void launch_repack_nodes(const uint32_t *src, uint32_t n, const float smin[3], const float sext[3],
-                         const uint32_t *order, const uint32_t *rank, float4 *dst, hipStream_t s);
+                         const uint32_t *order, const uint32_t *rank, const LeafRegions &leaves, float4 *dst,
+                         hipStream_t s);
 void launch_repack_tris(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s);
 void launch_repack_spheres(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s);
 void launch_repack_mats(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s);

@@ -182,7 +182,7 @@ __device__ __forceinline__ float draw(uint32_t &s) {
 // source numbering.
 __global__ void repack_nodes_kernel(const uint32_t *__restrict__ src, uint32_t n, float3 smin, float3 sext,
                                     const uint32_t *__restrict__ order, const uint32_t *__restrict__ rank,
-                                    float4 *__restrict__ dst) {
+                                    LeafRegions lr, float4 *__restrict__ dst) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
     uint32_t w[16];
@@ -191,10 +191,17 @@ __global__ void repack_nodes_kernel(const uint32_t *__restrict__ src, uint32_t n
     for (int k = 0; k < 16; k++) w[k] = (i < n) ? src[(size_t)from * 16 + k] : 0u;
 #pragma unroll
     for (int k = 12; k < 16; k++) {
-        const uint32_t idx = w[k] & 0x3FFFFFFFu;
-        // a node index beyond the array (the reference's empty slot is 0x3FFFFFFF) means the all-zero
-        // sentinel node n, as the traversal's own clamp would have it; no word is 0xFFFFFFFF afterwards
-        if ((w[k] >> 30) == 3u) w[k] = 0xC0000000u | (idx < n ? (rank ? rank[idx] : idx) : n);
+        // The child word becomes type << 30 | the record's position, in units of 32 bytes from the first
+        // node record (DevScene).  An index beyond its array -- the reference's empty slot is node
+        // 0x3FFFFFFF -- names the all-zero record that ends every array, which is what such a read
+        // delivers in the reference (robust buffer access).  No word is 0xFFFFFFFF afterwards.
+        const uint32_t type = w[k] >> 30, idx = w[k] & 0x3FFFFFFFu;
+        uint32_t unit;
+        if (type == 3u) unit = 4u * (idx < n ? (rank ? rank[idx] : idx) : n);
+        else if (type == 0u) unit = lr.unit_tris + 2u * min(idx, lr.n_tris);
+        else if (type == 1u) unit = lr.unit_spheres + min(idx, lr.n_spheres);
+        else unit = lr.unit_boxes + min(idx, lr.n_boxes);
+        w[k] = (type << 30) | unit;
     }
     const float mn[3] = {smin.x, smin.y, smin.z}, ex[3] = {sext.x, sext.y, sext.z};
     float lo[3][4], hi[3][4];
@@ -291,9 +298,11 @@ __global__ void repack_mats_kernel(const uint32_t *__restrict__ src, uint32_t n,
 static inline unsigned grid_for(uint32_t n_plus_sentinel) { return (n_plus_sentinel + 255u) / 256u; }
 
 void launch_repack_nodes(const uint32_t *src, uint32_t n, const float smin[3], const float sext[3],
-                         const uint32_t *order, const uint32_t *rank, float4 *dst, hipStream_t s) {
+                         const uint32_t *order, const uint32_t *rank, const LeafRegions &leaves, float4 *dst,
+                         hipStream_t s) {
     hipLaunchKernelGGL(repack_nodes_kernel, dim3(grid_for(n + 1)), dim3(256), 0, s, src, n,
-                       make_float3(smin[0], smin[1], smin[2]), make_float3(sext[0], sext[1], sext[2]), order, rank, dst);
+                       make_float3(smin[0], smin[1], smin[2]), make_float3(sext[0], sext[1], sext[2]), order, rank,
+                       leaves, dst);
 }
 void launch_repack_tris(const uint32_t *src, uint32_t n, float4 *dst, hipStream_t s) {
     hipLaunchKernelGGL(repack_tris_kernel, dim3(grid_for(n + 1)), dim3(256), 0, s, src, n, dst);
@@ -413,6 +422,16 @@ __device__ __forceinline__ bool box_distance(v3 O, v3 D, v3 b0, v3 b1, float &t_
 // child boxes, sort, visit far to near (leaves are intersected at once, inner children pushed).
 // `stack` is this lane's column of the LDS stack (element stride STRIDE), `spill` its private
 // overflow array.  best/best_code: distance and metadata word of the best hit so far.
+// A child word of a device node record (type << 30 | position, see DevScene) as the reference's
+// word (type << 30 | index); 0xFFFFFFFF, "no hit", stays.  A leaf index that lay beyond its array
+// comes back as the index of the array's closing zero record.
+__device__ __forceinline__ uint32_t reference_word(const DevScene &sc, uint32_t w) {
+    const uint32_t type = w >> 30, unit = w & 0x3FFFFFFFu;
+    const uint32_t idx = type == 0u ? (unit - sc.unit_tris) >> 1 : type == 1u ? unit - sc.unit_spheres
+                       : type == 2u ? unit - sc.unit_boxes : unit >> 2;
+    return w == 0xFFFFFFFFu ? w : (type << 30) | idx;
+}
+
 // The leaves of the node visited last that are still to be intersected, in one of two forms.
 // As a list (the kernels with leaf steps of their own): v0.. are the pending leaves' words, v0 the
 // next one, pend their number -- the next word is at hand when a leaf step starts, before its loads.
@@ -465,7 +484,7 @@ __device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeR
         nd.lox = ld4(np), nd.hix = ld4(np + 1), nd.loy = ld4(np + 2), nd.mt = ld4(np + 3);
         return;
     }
-    ni = min(ni, sc.n_nodes);  // out-of-range -> the zero-source sentinel node
+    // ni: the node's position in units of 32 bytes (4 per node), never beyond the closing record
     if (TOP > 0) {
         // Written in assembly so that the two cases may be in flight together: in a wavefront whose
         // lanes split between them the compiler would wait for all global loads before it issues the
@@ -477,8 +496,8 @@ __device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeR
         // statement under explicit execution masks, which needs no such check, costs 1.3 % of a
         // frame on cache-resident scenes.)
         vec4f a0, a1, a2, a3, a4, a5, a6;
-        if (ni < (uint32_t)TOP) {
-            const uint32_t addr = (uint32_t)(uintptr_t)top + ni * (RT_TOP_STRIDE * 16u);
+        if (ni < 4u * (uint32_t)TOP) {
+            const uint32_t addr = (uint32_t)(uintptr_t)top + ni * (RT_TOP_STRIDE * 4u);
             asm volatile(
                 "ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:32\n\t"
                 "ds_read_b128 %3, %7 offset:48\n\tds_read_b128 %4, %7 offset:64\n\tds_read_b128 %5, %7 offset:80\n\t"
@@ -487,7 +506,7 @@ __device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeR
                 : "v"(addr)
                 : "memory");
         } else {
-            const float4 *np = sc.nodes + (size_t)ni * kNodeVec;
+            const float4 *np = sc.nodes + (size_t)ni * 2u;
             asm volatile(
                 "global_load_dwordx4 %0, %7, off\n\tglobal_load_dwordx4 %1, %7, off offset:16\n\t"
                 "global_load_dwordx4 %2, %7, off offset:32\n\tglobal_load_dwordx4 %3, %7, off offset:48\n\t"
@@ -511,7 +530,7 @@ __device__ __forceinline__ void node_load(const DevScene &sc, uint32_t ni, NodeR
         nd.mt = make_float4(a6.x, a6.y, a6.z, a6.w);
         return;
     }
-    GlobalNodes np = (GlobalNodes)sc.nodes + (size_t)ni * kNodeVec;  // no LDS copy: plain loads
+    GlobalNodes np = (GlobalNodes)sc.nodes + (size_t)ni * 2u;  // no LDS copy: plain loads
     nd.lox = ld4(np), nd.hix = ld4(np + 1), nd.loy = ld4(np + 2), nd.hiy = ld4(np + 3), nd.loz = ld4(np + 4),
     nd.hiz = ld4(np + 5), nd.mt = ld4(np + 6);
 }
@@ -637,8 +656,12 @@ __device__ __forceinline__ void node_test(const DevScene &sc, const NodeRegs &nd
     if (MASK) {
         // the words stay where the sort left them, one bit per word marks the leaves
         ll.v0 = m3, ll.v1 = m2, ll.v2 = m1, ll.v3 = m0;
-        ll.pend = (m3 < 0xC0000000u ? 1u : 0u) | (m2 < 0xC0000000u ? 2u : 0u) | (m1 < 0xC0000000u ? 4u : 0u) |
-                  (m0 < 0xC0000000u ? 8u : 0u);
+        // (doubling and adding the next bit is one add-with-carry per word)
+        uint32_t pend = m0 < 0xC0000000u ? 1u : 0u;
+        pend = pend + pend + (m1 < 0xC0000000u ? 1u : 0u);
+        pend = pend + pend + (m2 < 0xC0000000u ? 1u : 0u);
+        pend = pend + pend + (m3 < 0xC0000000u ? 1u : 0u);
+        ll.pend = pend;
         return;
     }
     // build the list by prepending in the order k = 0..3, so that k = 3 ends up in front
@@ -667,7 +690,7 @@ __device__ __forceinline__ void node_part(const DevScene &sc, v3 O, v3 ID, float
 }
 
 // Intersects the first pending leaf of the list (compute.glsl:299-322).
-template <bool STATS>
+template <bool STATS, bool FAST = false>
 __device__ __forceinline__ void leaf_one(const DevScene &sc, v3 O, v3 D, float &best, uint32_t &best_code,
                                          LeafList &ll, LaneStats &st) {
     uint32_t meta = ll.v0;  // list form
@@ -678,16 +701,18 @@ __device__ __forceinline__ void leaf_one(const DevScene &sc, v3 O, v3 D, float &
     uint32_t type = meta >> 30, idx = meta & 0x3FFFFFFFu;
     float t;
     bool hit;
+    // the words of the library's own tree (FAST) hold indices; those of the device node records positions
+    const float4 *rec = sc.nodes + (size_t)idx * 2u;
     if (type == 0u) {
-        const float4 *tp = sc.tris + (size_t)min(idx, sc.n_tris) * kTriVec;
+        const float4 *tp = FAST ? sc.tris + (size_t)min(idx, sc.n_tris) * kTriVec : rec;
         if (STATS) st.tri++;
         hit = tri_distance(O, D, tp[0], tp[1], tp[2], t);
     } else if (type == 1u) {
-        const float4 *spn = sc.spheres + (size_t)min(idx, sc.n_spheres) * kSphereVec;
+        const float4 *spn = FAST ? sc.spheres + (size_t)min(idx, sc.n_spheres) * kSphereVec : rec;
         if (STATS) st.sph++;
         hit = sphere_distance(O, D, spn[0], t);
     } else {
-        const float4 *bp = sc.boxes + (size_t)min(idx, sc.n_boxes) * 2;
+        const float4 *bp = FAST ? sc.boxes + (size_t)min(idx, sc.n_boxes) * 2 : rec;
         float4 b0 = bp[0], b1 = bp[1];
         if (STATS) st.box++;
         hit = box_distance(O, D, V(b0.x, b0.y, b0.z), V(b1.x, b1.y, b1.z), t);
@@ -705,7 +730,7 @@ __device__ __forceinline__ void node_step(const DevScene &sc, v3 O, v3 D, v3 ID,
                                           LdsTop top = nullptr) {
     LeafList ll;
     node_part<STATS, STRIDE, LDS_DEPTH, TOP, FAST>(sc, O, ID, best, sp, stack, spill, ll, st, top);
-    while (ll.pend != 0u) leaf_one<STATS>(sc, O, D, best, best_code, ll, st);
+    while (ll.pend != 0u) leaf_one<STATS, FAST>(sc, O, D, best, best_code, ll, st);
 }
 
 // The whole traversal of one ray (compute.glsl:225-330) with ONE kind of step for nodes and
@@ -748,12 +773,12 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
     bool &have = w.have;
     {
         const uint32_t type = cur >> 30, idx = cur & 0x3FFFFFFFu;
-        const uint32_t ni = idx;  // never beyond the sentinel: the repack has clamped every child word that names a node
-        const bool in_lds = type == 3u && ni < (uint32_t)TOP;
+        // idx: the record's position in units of 32 bytes from the first node (4 per node)
+        const bool in_lds = type == 3u && idx < 4u * (uint32_t)TOP;
         vec4f a0, a1, a2, a3, a4, a5, a6;  // in flight until the waits below: see node_load and tools/check_isa.py
         uintptr_t rec = 0;  // address of the item's record
         if (in_lds) {
-            const uint32_t addr = (uint32_t)(uintptr_t)top + ni * (RT_TOP_STRIDE * 16u);
+            const uint32_t addr = (uint32_t)(uintptr_t)top + idx * (RT_TOP_STRIDE * 4u);
             asm volatile(
                 "ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:32\n\t"
                 "ds_read_b128 %3, %7 offset:48\n\tds_read_b128 %4, %7 offset:64\n\tds_read_b128 %5, %7 offset:80\n\t"
@@ -762,10 +787,7 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
                 : "v"(addr)
                 : "memory");
         } else {
-            if (type == 3u) rec = (uintptr_t)(sc.nodes + (size_t)ni * kNodeVec);
-            else if (type == 0u) rec = (uintptr_t)(sc.tris + (size_t)min(idx, sc.n_tris) * kTriVec);
-            else if (type == 1u) rec = (uintptr_t)(sc.spheres + (size_t)min(idx, sc.n_spheres) * kSphereVec);
-            else rec = (uintptr_t)(sc.boxes + (size_t)min(idx, sc.n_boxes) * 2);
+            rec = (uintptr_t)(sc.nodes + (size_t)idx * 2u);  // whatever the kind of record
             // Seven loads cover the first 112 bytes of the record's 128-byte line, except for a
             // triangle: its first three start at the record itself, so that its 48 bytes arrive in
             // a0..a2 whichever half of the line it lies in, and the other four, which its lane does not
@@ -831,9 +853,10 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
             if (STATS) st.max_sp = max(st.max_sp, (uint32_t)sp);
             popped = stack_pop<STRIDE, LDS_DEPTH>(sp, stack, spill);
         }
-        // (with pend == 0 the selection below yields v3 and leaves pend at 0)
-        const int j = __builtin_ctz(ll.pend | 8u);
-        const uint32_t leaf = j == 0 ? ll.v0 : j == 1 ? ll.v1 : j == 2 ? ll.v2 : ll.v3;
+        // (with pend == 0 nothing is taken from the list: whatever the selection yields is dropped)
+        const int j = __builtin_ctz(ll.pend);
+        const uint32_t leaf_a = j == 0 ? ll.v0 : ll.v1, leaf_b = j == 2 ? ll.v2 : ll.v3;
+        const uint32_t leaf = j < 2 ? leaf_a : leaf_b;
         ll.pend &= ll.pend - 1u;
         cur = from_list ? leaf : popped;
         have = from_list || from_stack;
@@ -854,6 +877,7 @@ __device__ __forceinline__ void traverse_unified(const DevScene &sc, v3 O, v3 D,
     // wait here (encoding: vmcnt(0), the other counters at their maxima) keeps those out of the loop.
     __builtin_amdgcn_s_waitcnt(0x0F70);
     while (w.have) walk_step<STATS, STRIDE, LDS_DEPTH, TOP>(sc, O, D, ID, best, best_code, w, stack, spill, st, top);
+    best_code = reference_word(sc, best_code);
 }
 
 // Surface attributes of the accepted primitive, derived from (O, D, t, code) exactly as the
@@ -1252,6 +1276,7 @@ __device__ __forceinline__ void trace_body(const TraceParams &p) {
                 if (!FAST) __builtin_amdgcn_s_waitcnt(0x0F70);  // as in traverse_unified: no compiler-known load pending in the loop
                 while (sp > 0)
                     node_step<STATS, RT_TRACE_BLOCK, RT_STACK_LDS, TOP, FAST>(sc, ps.O, ps.D, ID, best, code, sp, stack, spill, st, top);
+                if (!FAST) code = reference_word(sc, code);
             }
             nrays++;
             bool exists;
@@ -1393,7 +1418,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_regroup_kernel(T
             // a finished ray leaves its result in its home column
             if (has && !w.have) {
                 lds_stack[slot] = f2u(best);
-                lds_stack[RT_BLOCK + slot] = code;
+                lds_stack[RT_BLOCK + slot] = reference_word(sc, code);
                 if (STATS) lds_stack[2 * RT_BLOCK + slot] = visits;
                 has = false;
             }
@@ -1661,7 +1686,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_EXTEND_MIN_WAVES) void extend_kernel(D
         uint32_t n_idle = (uint32_t)__popcll(idle_mask);
         if (n_idle >= refill_threshold || n_idle == 64u) {
             if (idle && ray >= 0) {
-                hits[ray] = make_float2(best, u2f(code));
+                hits[ray] = make_float2(best, u2f(reference_word(sc, code)));
                 if (STATS && aux) atomicAdd(aux + (size_t)pix_this_ray * 16 + 3, nodes_this_ray);
                 nrays_done++;
                 ray = -1;

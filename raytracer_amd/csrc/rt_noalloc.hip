@@ -134,8 +134,11 @@ extern "C" int rt_render_noalloc(int device, const rt_scene_view *sv, int width,
     // regions are rewritten for elements [0, n] (n = the zero-source sentinel), and nothing reads
     // beyond n, so a smaller scene after a larger one sees none of the stale tail
     NA_HIP(hipMemsetAsync(counters, 0, sizeof(Counters) * kCounterStripes, s));
+    // the leaf regions follow the nodes in the same array: positions in units of 32 bytes from the first node
+    const LeafRegions leaves = {(uint32_t)((kOffTris - kOffNodes) / 32), (uint32_t)((kOffSpheres - kOffNodes) / 32),
+                                (uint32_t)((kOffBoxes - kOffNodes) / 32), sv->n_triangles, sv->n_spheres, sv->n_boxes};
     launch_repack_nodes(static_cast<const uint32_t *>(sv->bvh), sv->n_nodes, sv->scene_min, sv->scene_extent, nullptr,
-                        nullptr, nodes, s);
+                        nullptr, leaves, nodes, s);
     launch_repack_tris(static_cast<const uint32_t *>(sv->triangles), sv->n_triangles, tris, s);
     launch_repack_spheres(static_cast<const uint32_t *>(sv->spheres), sv->n_spheres, spheres, s);
     launch_copy_raw32(static_cast<const uint32_t *>(sv->boxes), sv->n_boxes, boxes, s);
@@ -157,6 +160,7 @@ extern "C" int rt_render_noalloc(int device, const rt_scene_view *sv, int width,
     p.scene.n_mats = sv->n_materials;
     p.scene.fnodes = nullptr;  // fast mode is a context feature; this entry point renders the reference's tree
     p.scene.n_fnodes = 0;
+    p.scene.unit_tris = leaves.unit_tris, p.scene.unit_spheres = leaves.unit_spheres, p.scene.unit_boxes = leaves.unit_boxes;
     for (int i = 0; i < 16; i++) p.scene.inv_vp[i] = sv->inv_view_proj[i];
     for (int i = 0; i < 3; i++) {
         p.scene.eye[i] = sv->eye[i];
