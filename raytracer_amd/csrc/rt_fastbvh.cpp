@@ -9,7 +9,8 @@
 //   * collapsed to 4 children per node (the child with the largest surface is opened first);
 //   * child boxes quantised to 8 bits per plane relative to the node's own box and rounded
 //     OUTWARD (checked with the exact arithmetic the traversal decodes with), so no hit is lost;
-//   * nodes in breadth-first order (the first ones are cached in LDS).
+//   * the first kFastTopNodes nodes, which the kernels keep in LDS, are the root and, grown from it, the
+//     nodes with the largest boxes (the ones a ray is most likely to visit); the rest breadth-first.
 // Node record (16 words = 64 bytes; the reference's node is 64 bytes too but needs a divide per
 // plane to decode, which is why the default mode expands it to 128 bytes on upload):
 //   [0..2] origin xyz (f32)   [3] biased exponents ex | ey << 8 | ez << 16 (scale = 2^(e-127))
@@ -329,6 +330,49 @@ int build_fast_bvh(const uint32_t *tris, uint32_t n_tris, const uint32_t *sphere
         out.nodes.insert(out.nodes.end(), w, w + 16);
     }
     out.n_nodes = (uint32_t)(out.nodes.size() / 16);
+    {
+        // Renumber: the nodes the kernels copy into LDS are chosen by box area from the root down
+        // (always the frontier node with the largest box, ties to the smaller index), everything
+        // else keeps its breadth-first order behind them.
+        const uint32_t n = out.n_nodes;
+        std::vector<uint32_t> order, rank(n, 0xFFFFFFFFu);
+        order.reserve(n);
+        auto emit = [&](uint32_t node) { rank[node] = (uint32_t)order.size(), order.push_back(node); };
+        auto less = [](const std::pair<float, uint32_t> &x, const std::pair<float, uint32_t> &y) {
+            return x.first < y.first || (x.first == y.first && x.second > y.second);
+        };
+        std::vector<std::pair<float, uint32_t>> heap;
+        auto push_children = [&](uint32_t node) {
+            for (int k = 0; k < 4; k++) {
+                const uint32_t w = out.nodes[(size_t)node * 16 + 12 + k];
+                if (w == 0xFFFFFFFFu || (w >> 30) != 3u) continue;
+                const uint32_t child = w & 0x3FFFFFFFu;
+                const float area = b.nodes[queue[child]].box.half_area();
+                heap.emplace_back(area == area ? area : 0.0f, child);
+                std::push_heap(heap.begin(), heap.end(), less);
+            }
+        };
+        emit(0);
+        push_children(0);
+        while (!heap.empty() && order.size() < kFastTopNodes) {
+            std::pop_heap(heap.begin(), heap.end(), less);
+            const uint32_t node = heap.back().second;
+            heap.pop_back();
+            emit(node);
+            push_children(node);
+        }
+        for (uint32_t i = 0; i < n; i++)
+            if (rank[i] == 0xFFFFFFFFu) emit(i);
+        std::vector<uint32_t> moved((size_t)n * 16);
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t *src = &out.nodes[(size_t)order[i] * 16];
+            uint32_t *dst = &moved[(size_t)i * 16];
+            std::memcpy(dst, src, 64);
+            for (int k = 12; k < 16; k++)
+                if (dst[k] != 0xFFFFFFFFu && (dst[k] >> 30) == 3u) dst[k] = 0xC0000000u | rank[dst[k] & 0x3FFFFFFFu];
+        }
+        out.nodes.swap(moved);
+    }
     out.nodes.insert(out.nodes.end(), empty, empty + 16);  // the sentinel
     return 0;
 }

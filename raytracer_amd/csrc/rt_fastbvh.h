@@ -7,6 +7,9 @@
 
 namespace rt {
 
+// leading nodes of the fast-mode tree that the kernels keep in LDS (64 bytes each: 12 KB per workgroup)
+constexpr uint32_t kFastTopNodes = 192;
+
 struct FastBvh {
     std::vector<uint32_t> nodes;  // 16 words per node: n_nodes nodes plus one all-empty sentinel
     uint32_t n_nodes = 0;

@@ -26,8 +26,8 @@ namespace rt {
 //   [2] diffuse albedo.rgb (colour*(1-metallic)), f0  [3] ior, ggx a2, metallic, 0
 // Boxes and planes keep the reference layout (2 x float4 each).
 #ifndef RT_LDS_TOP
-#define RT_LDS_TOP 109     // leading (breadth-first) nodes a workgroup of the megakernel keeps in LDS: four levels (85) plus
-                           // what fits in the 20 KB a workgroup may use while 8 of them share a CU; 0 = none
+#define RT_LDS_TOP 109     // leading node records (the top of the tree) a workgroup of the megakernel keeps in LDS: what
+                           // fits in the 20 KB a workgroup may use while 8 of them share a CU; 0 = none
 #endif
 constexpr uint32_t kLdsTopNodes = RT_LDS_TOP;
 constexpr int kNodeVec = 8;

@@ -14,7 +14,7 @@
 namespace rt {
 
 #define RT_BLOCK 256
-// RT_LDS_TOP (rt_internal.h): number of leading (breadth-first) nodes kept in LDS per workgroup
+// RT_LDS_TOP (rt_internal.h): number of leading device node records kept in LDS per workgroup
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 4   // megakernel: wavefronts per workgroup, each an 8x8 quarter of a 16x16 tile (the regrouping kernel assumes 4)
 #endif
@@ -36,7 +36,7 @@ namespace rt {
 #define RT_MIN_WAVES 8  // megakernel: waves per SIMD the register allocator must leave room for
 #endif
 #ifndef RT_FAST_TOP
-#define RT_FAST_TOP 192    // fast mode: leading nodes (64 bytes each) kept in LDS per workgroup: 12 KB
+#define RT_FAST_TOP 192    // fast mode: leading nodes (64 bytes each) kept in LDS per workgroup: 12 KB (kFastTopNodes)
 #endif
 // RT_MACRO (rt_internal.h): megakernel tile placement, macro tile = RT_MACRO x RT_MACRO tiles of 16x16 pixels, dealt to the XCDs in turn
 #ifndef RT_EXT_STACK_LDS
@@ -175,9 +175,10 @@ __device__ __forceinline__ float draw(uint32_t &s) {
 // ------------------------------------------------------------------------------------------
 // BVH node, decoded once here, compute.glsl:244-261: f = float(q)/65535.0 ; coord = scene_min + f*scene_extent
 // Device record i is built from source node order[i]; child indices are rewritten with
-// rank[] (rank[order[i]] = i).  The renumbering puts the nodes in breadth-first order from the
-// root, so the top levels of the tree are the first records; nothing outside the traversal ever
-// sees a node index, so results are unchanged.  Indices that point outside the buffer stay as
+// rank[] (rank[order[i]] = i).  The renumbering (node_order in rt_api.cpp) puts the nodes a ray is
+// most likely to visit -- the root and, grown from it, the nodes with the largest boxes -- first,
+// where the kernels' LDS copy takes them from, and the rest in breadth-first order; nothing outside
+// the traversal ever sees a node index, so results are unchanged.  Indices that point outside the buffer stay as
 // they are (they select the all-zero record either way).  order == rank == nullptr keeps the
 // source numbering.
 __global__ void repack_nodes_kernel(const uint32_t *__restrict__ src, uint32_t n, float3 smin, float3 sext,
@@ -465,8 +466,8 @@ __device__ __forceinline__ float4 ld4(GlobalNodes p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// Issues the loads of node ni.  TOP > 0: the first TOP nodes (breadth-first numbering, i.e. the top
-// levels of the tree) are read from the workgroup's LDS copy `top` instead of through the vector
+// Issues the loads of node ni.  TOP > 0: the first TOP nodes (the top of the tree in the device
+// numbering) are read from the workgroup's LDS copy `top` instead of through the vector
 // memory pipeline, which is what bounds this kernel.
 // FAST (the opt-in fast mode, not the reference's data): the node is one of the library's own
 // 64-byte records (rt_fastbvh.cpp), 4 x 16 bytes: n0 = origin.xyz + exponents, n1 = lo_x hi_x lo_y
@@ -1233,7 +1234,7 @@ __device__ __forceinline__ void trace_body(const TraceParams &p) {
     uint32_t spill[RT_STACK_SPILL];
     const DevScene &sc = p.scene;
     constexpr int TOP = FAST ? RT_FAST_TOP : RT_LDS_TOP;
-    // the workgroup's copy of the top of the tree (breadth-first numbering: the first records)
+    // the workgroup's copy of the top of the tree (the first records of the device numbering)
     __shared__ float4 lds_top[RT_LDS_TOP * RT_TOP_STRIDE > RT_FAST_TOP * 4 ? RT_LDS_TOP * RT_TOP_STRIDE : RT_FAST_TOP * 4];
     if (FAST) {
         for (uint32_t k = threadIdx.x; k < RT_FAST_TOP * 4u; k += RT_TRACE_BLOCK)

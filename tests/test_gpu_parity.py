@@ -818,11 +818,12 @@ def test_traversal_variant_can_be_fixed_per_context():
         r.close()
 
 
-@pytest.mark.parametrize("knobs", [{"RT_NODE_LAYOUT": "1"}, {"RT_NODE_LAYOUT": "2"},
+@pytest.mark.parametrize("knobs", [{"RT_NODE_LAYOUT": "0"}, {"RT_NODE_LAYOUT": "1"}, {"RT_NODE_LAYOUT": "2"},
                                    {"RT_PIPELINE": "wave", "RT_WAVE_BIN": "1"}])
 def test_experiment_knobs_change_no_pixel(knobs):
-    """RT_NODE_LAYOUT (depth-first subtrees / three-level treelets below the LDS copy instead of
-    breadth-first order) renumbers the device node records only, and RT_WAVE_BIN regroups the
+    """RT_NODE_LAYOUT (which nodes form the LDS copy -- the breadth-first top instead of the default,
+    the nodes with the largest boxes -- and depth-first subtrees / three-level treelets below it instead
+    of breadth-first order) renumbers the device node records only, and RT_WAVE_BIN regroups the
     wavefront pipeline's rays by direction octant between bounces: images and first hits stay the
     reference shader's."""
     import os
