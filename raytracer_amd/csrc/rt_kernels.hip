@@ -457,6 +457,7 @@ struct NodeRegs {
 typedef float vec4f __attribute__((ext_vector_type(4)));  // plain vector: may carry an address space
 using LdsTop = const __attribute__((address_space(3))) vec4f *;
 using GlobalNodes = const __attribute__((address_space(1))) vec4f *;
+using ConstVec = const __attribute__((address_space(4))) vec4f *;  // read-only for the kernel's lifetime: uniform addresses load through the scalar cache
 __device__ __forceinline__ float4 ld4(LdsTop p) {
     vec4f v = *p;
     return make_float4(v.x, v.y, v.z, v.w);
@@ -777,7 +778,31 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
         // idx: the record's position in units of 32 bytes from the first node (4 per node)
         const bool in_lds = type == 3u && idx < 4u * (uint32_t)TOP;
         vec4f a0, a1, a2, a3, a4, a5, a6;  // in flight until the waits below: see node_load and tools/check_isa.py
-        uintptr_t rec = 0;  // address of the item's record
+        uintptr_t rec;
+        // The slowest ray of 64 sets the pace of a bounce: a wavefront spends a tenth of its steps with a
+        // single ray left.  That ray's record then comes through the scalar data cache (read only; the
+        // address made uniform with readfirstlane): such a step costs the vector-memory return path,
+        // which bounds this kernel, nothing.  The values stay in scalar registers until the waits
+        // below are over, so nothing of this arm touches a vector register that the other arms load
+        // into.  (RT_SOLO_SCALAR=0: A/B builds without it.  Measured and not kept: the scalar path
+        // for two to four lanes one after the other, and for one lane off the LDS copy while others
+        // are on it -- both slower than the vector loads.)
+#ifndef RT_SOLO_SCALAR
+#define RT_SOLO_SCALAR 1
+#endif
+        const uint64_t live = __builtin_amdgcn_ballot_w64(true);
+        const bool solo = RT_SOLO_SCALAR && (live & (live - 1u)) == 0u;
+        // the address of the item's record (whatever its kind) and of the two runs of 16-byte vectors
+        // fetched for it.  Seven loads cover the first 112 bytes of the record's 128-byte line, except
+        // for a triangle: its first three start at the record itself, so that its 48 bytes arrive in
+        // a0..a2 whichever half of the line it lies in, and the other four, which its lane does not
+        // use, re-read the start of the line -- no second line is touched, nothing is read beyond
+        // a buffer.  (Only the low address word differs: records do not straddle lines.)
+        rec = (uintptr_t)(sc.nodes + (size_t)idx * 2u);
+        const uint32_t rec_lo = (uint32_t)rec, line_lo = rec_lo & ~127u;
+        const uint32_t first_lo = type == 0u ? rec_lo : line_lo, rest_lo = type == 0u ? line_lo : line_lo + 48u;
+        vec4f c0, c1, c2, c3, c4, c5, c6;  // the scalar arm's copy of the record
+        bool from_scalar = false;
         if (in_lds) {
             const uint32_t addr = (uint32_t)(uintptr_t)top + idx * (RT_TOP_STRIDE * 4u);
             asm volatile(
@@ -787,17 +812,15 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6)
                 : "v"(addr)
                 : "memory");
+        } else if (solo) {
+            const uintptr_t base = (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(rec >> 32)) << 32;
+            ConstVec first = (ConstVec)(base | (uint32_t)__builtin_amdgcn_readfirstlane(first_lo));
+            ConstVec rest = (ConstVec)(base | (uint32_t)__builtin_amdgcn_readfirstlane(rest_lo));
+            c0 = first[0], c1 = first[1], c2 = first[2], c3 = rest[0], c4 = rest[1], c5 = rest[2], c6 = rest[3];
+            from_scalar = true;
         } else {
-            rec = (uintptr_t)(sc.nodes + (size_t)idx * 2u);  // whatever the kind of record
-            // Seven loads cover the first 112 bytes of the record's 128-byte line, except for a
-            // triangle: its first three start at the record itself, so that its 48 bytes arrive in
-            // a0..a2 whichever half of the line it lies in, and the other four, which its lane does not
-            // use, re-read the start of the line -- no second line is touched, nothing is read beyond
-            // a buffer.  (Only the low address word differs: records do not straddle lines.)
-            const uint32_t lo = (uint32_t)rec, line_lo = lo & ~127u;
             const uintptr_t hi = rec & ~(uintptr_t)0xFFFFFFFFu;
-            const uintptr_t first = hi | (type == 0u ? lo : line_lo);
-            const uintptr_t rest = hi | (type == 0u ? line_lo : line_lo + 48u);
+            const uintptr_t first = hi | first_lo, rest = hi | rest_lo;
             asm volatile(
                 "global_load_dwordx4 %0, %7, off\n\tglobal_load_dwordx4 %1, %7, off offset:16\n\t"
                 "global_load_dwordx4 %2, %7, off offset:32\n\tglobal_load_dwordx4 %3, %8, off\n\t"
@@ -815,6 +838,7 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
         asm volatile("s_waitcnt vmcnt(2) lgkmcnt(2)" : "+v"(a4));
         asm volatile("s_waitcnt vmcnt(1) lgkmcnt(1)" : "+v"(a5));
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a6));
+        if (from_scalar) a0 = c0, a1 = c1, a2 = c2, a3 = c3, a4 = c4, a5 = c5, a6 = c6;
 #define F4(a) make_float4(a.x, a.y, a.z, a.w)
         if (type == 3u) {
             if (STATS) st.nodes++;
