@@ -46,7 +46,7 @@ def wave_rays(tr, tx, ty):
     """[lane][bounce] -> (nsteps, leafcounts) for the 8x8 pixel tile (tx, ty)."""
     t = tr[ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8].reshape(64, 8, REC)
     n = t[:, :, 0].astype(np.int32) | (t[:, :, 1].astype(np.int32) << 8)
-    return n, t[:, :, 2:]
+    return n, t[:, :, 2:] & 0x7F   # (bit 7 of a visit's byte: the popped node lay beyond the best hit)
 
 
 def lockstep(n, lc):
