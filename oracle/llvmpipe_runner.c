@@ -30,6 +30,18 @@
  * framebuffer re-attached, as Renderer.update_size does (renderer.py:347-382);
  * the count of accumulated frames goes on, as the reference's does.
  * stdout: one JSON line with per-frame milliseconds (glFinish-bounded).
+ *
+ * Present mode (no compute dispatch):
+ *   llvmpipe_runner --present-vs V.glsl --present-fs F.glsl --present-in IMG.bin
+ *       --present-out OUT.bin --w W --h H
+ * IMG.bin (W*H*4 f32, row 0 = bottom) is put into an RGBA32F texture made as
+ * the reference makes its accumulation texture (renderer.py:399-433) with
+ * glTexSubImage2D -- what a host does with an accumulation image it got from
+ * elsewhere -- and the reference's present pass (renderer.py:290-300: the
+ * upscale program drawn over the screen quad, blending on as everywhere) is
+ * drawn into an RGBA8 framebuffer of the same size, which stands for the
+ * window's default framebuffer.  OUT.bin receives its W*H*4 bytes, row 0 =
+ * bottom.
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -84,6 +96,7 @@ static double now_ms(void) {
 int main(int argc, char **argv) {
     const char *shader = NULL, *uni = NULL, *out = NULL;
     const char *screen_vs = NULL, *screen_fs = NULL, *acc_out = NULL;
+    const char *present_vs = NULL, *present_fs = NULL, *present_in = NULL, *present_out = NULL;
     const char *buf_path[16] = {0};
     int W = 640, H = 360, f0 = 0, f1 = 1, reps = 1, recreate_at = -1;
     float bounces = 2.0f;
@@ -100,6 +113,10 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--screen-fs")) screen_fs = argv[++i];
         else if (!strcmp(argv[i], "--acc-out")) acc_out = argv[++i];
         else if (!strcmp(argv[i], "--recreate-at")) recreate_at = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--present-vs")) present_vs = argv[++i];
+        else if (!strcmp(argv[i], "--present-fs")) present_fs = argv[++i];
+        else if (!strcmp(argv[i], "--present-in")) present_in = argv[++i];
+        else if (!strcmp(argv[i], "--present-out")) present_out = argv[++i];
         else if (!strcmp(argv[i], "--spheres")) buf_path[5] = argv[++i];
         else if (!strcmp(argv[i], "--planes")) buf_path[6] = argv[++i];
         else if (!strcmp(argv[i], "--boxes")) buf_path[7] = argv[++i];
@@ -108,7 +125,10 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--tris")) buf_path[12] = argv[++i];
         else { fprintf(stderr, "unknown arg %s\n", argv[i]); return 2; }
     }
-    if (!shader || !uni || !out) die("need --shader --uniforms --out");
+    const int present = present_vs || present_fs || present_in || present_out;
+    if (present && !(present_vs && present_fs && present_in && present_out))
+        die("--present-vs, --present-fs, --present-in and --present-out go together");
+    if (!present && (!shader || !uni || !out)) die("need --shader --uniforms --out");
     int accumulate = screen_vs || screen_fs || acc_out;
     if (accumulate && !(screen_vs && screen_fs && acc_out))
         die("--screen-vs, --screen-fs and --acc-out go together");
@@ -199,9 +219,89 @@ int main(int argc, char **argv) {
     GLF(PFNGLVIEWPORTPROC, glViewport);
     GLF(PFNGLENABLEPROC, glEnable);
     GLF(PFNGLBLENDFUNCPROC, glBlendFunc);
+    GLF(PFNGLTEXSUBIMAGE2DPROC, glTexSubImage2D);
+    GLF(PFNGLCLEARCOLORPROC, glClearColor);
+    GLF(PFNGLCLEARPROC, glClear);
 
     fprintf(stderr, "GL_RENDERER: %s\nGL_VERSION: %s\n", (const char *)glGetString(GL_RENDERER),
             (const char *)glGetString(GL_VERSION));
+
+    if (present) {
+        const char *path[2] = {present_vs, present_fs};
+        const GLenum kind[2] = {GL_VERTEX_SHADER, GL_FRAGMENT_SHADER};
+        GLuint pprog = glCreateProgram();
+        GLint pok = 0;
+        for (int i = 0; i < 2; i++) {
+            size_t slen;
+            char *src = read_file(path[i], &slen);
+            GLuint sh = glCreateShader(kind[i]);
+            const char *srcs[1] = {src};
+            glShaderSource(sh, 1, srcs, NULL);
+            glCompileShader(sh);
+            glGetShaderiv(sh, GL_COMPILE_STATUS, &pok);
+            if (!pok) {
+                char log[8192];
+                glGetShaderInfoLog(sh, sizeof log, NULL, log);
+                fprintf(stderr, "compile of %s failed:\n%s\n", path[i], log);
+                return 4;
+            }
+            glAttachShader(pprog, sh);
+            free(src);
+        }
+        glLinkProgram(pprog);
+        glGetProgramiv(pprog, GL_LINK_STATUS, &pok);
+        if (!pok) die("present program does not link");
+        size_t nin;
+        float *src_img = read_file(present_in, &nin);
+        if (nin != (size_t)W * H * 16) die("--present-in must hold W*H*4 f32");
+        GLuint ptex[2];
+        glGenTextures(2, ptex);
+        for (int i = 0; i < 2; i++) {
+            glBindTexture(GL_TEXTURE_2D, ptex[i]);
+            glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
+            glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
+            glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+            glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+            glTexStorage2D(GL_TEXTURE_2D, 1, i == 0 ? GL_RGBA32F : GL_RGBA8, W, H);
+        }
+        glBindTexture(GL_TEXTURE_2D, ptex[0]);
+        glTexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, W, H, GL_RGBA, GL_FLOAT, src_img);
+        /* quad of reference src/utils/opengl_utils.py:8-57: x y z u v per vertex */
+        static const float pquad[20] = {-1, 1, 0, 0, 1, -1, -1, 0, 0, 0, 1, 1, 0, 1, 1, 1, -1, 0, 1, 0};
+        GLuint pvao, pvbo, pfbo;
+        glGenVertexArrays(1, &pvao);
+        glGenBuffers(1, &pvbo);
+        glBindBuffer(GL_ARRAY_BUFFER, pvbo);
+        glBufferData(GL_ARRAY_BUFFER, sizeof pquad, pquad, GL_STATIC_DRAW);
+        glBindVertexArray(pvao);
+        glEnableVertexAttribArray(0);
+        glVertexAttribPointer(0, 3, GL_FLOAT, GL_FALSE, 5 * sizeof(float), (void *)0);
+        glEnableVertexAttribArray(1);
+        glVertexAttribPointer(1, 2, GL_FLOAT, GL_FALSE, 5 * sizeof(float), (void *)(3 * sizeof(float)));
+        glGenFramebuffers(1, &pfbo);
+        glBindFramebuffer(GL_FRAMEBUFFER, pfbo);
+        glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, ptex[1], 0);
+        if (glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) die("framebuffer incomplete");
+        glClearColor(1.0f, 1.0f, 1.0f, 1.0f); /* renderer.py:85 */
+        glClear(GL_COLOR_BUFFER_BIT);
+        glEnable(GL_BLEND); /* renderer.py:87-89 */
+        glBlendFunc(GL_SRC_ALPHA, GL_ONE_MINUS_SRC_ALPHA);
+        glUseProgram(pprog); /* renderer.py:290-296 */
+        glActiveTexture(GL_TEXTURE0);
+        glBindTexture(GL_TEXTURE_2D, ptex[0]);
+        glViewport(0, 0, W, H);
+        glDrawArrays(GL_TRIANGLE_STRIP, 0, 4);
+        glFinish();
+        unsigned char *bytes = malloc((size_t)W * H * 4);
+        glBindTexture(GL_TEXTURE_2D, ptex[1]);
+        glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, GL_UNSIGNED_BYTE, bytes);
+        FILE *fp = fopen(present_out, "wb");
+        if (!fp) die("cannot open --present-out");
+        if (fwrite(bytes, 4, (size_t)W * H, fp) != (size_t)W * H) die("short write");
+        fclose(fp);
+        printf("{\"w\": %d, \"h\": %d, \"present\": true, \"gl_error\": %u}\n", W, H, glGetError());
+        return 0;
+    }
 
     /* ---- programs ---- */
     const char *stage_path[3] = {shader, screen_vs, screen_fs};

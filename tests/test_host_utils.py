@@ -50,6 +50,21 @@ def test_png_is_clipped_quantised_and_upright(tmp_path):
     assert tuple(out[h - 1 - 2, 3]) == (128, 0, 0)
 
 
+def test_png_quantisation_is_the_reference_present_pass_on_llvmpipe(tmp_path):
+    """The reference shows the accumulation texture by drawing it with its upscale shaders into the
+    window's 8-bit framebuffer (renderer.py:290-300, upscale_fragment.glsl:8-17).  The fixture holds
+    what that pass produces on Mesa llvmpipe for a probe image -- every code, the ties between codes,
+    out-of-range values, infinities, NaN, random values (oracle/gen_present.py) -- uploaded the way a
+    host uploads a mapped accumulation image; the PNG writer must produce the same bytes."""
+    d = np.load(Path(__file__).parent / "golden" / "present" / "present_256x16.npz")
+    img, fb = d["image"], d["framebuffer"]
+    assert np.all(fb[..., 3] == 255)
+    assert np.array_equal(png.to_rgb8(img)[::-1], fb[..., :3])   # to_rgb8 returns rows top-down
+    p = tmp_path / "probe.png"
+    png.save_png(p, img)
+    assert np.array_equal(_decode_png(p)[::-1], fb[..., :3])
+
+
 def test_camera_controls_flag_a_change_and_move_as_the_reference_does():
     c = Camera()
     c.changed = False
