@@ -1,3 +1,8 @@
+#!/bin/bash
+# Which nodes form the workgroups' LDS copy: the breadth-first top of the tree (RT_NODE_LAYOUT=0) against the
+# largest boxes grown from the root (3, the default).  Bench timing of each, twice, in one run (figures move by
+# about 1 % from box to box, so only runs of one call compare), then the parity tests of the default pipeline.
+#   tools/ab_top.sh        (run on the GPU box)
 set -e
 OUT=gpurun_out/l3; mkdir -p $OUT
 for L in 0 3 0 3; do
