@@ -35,9 +35,8 @@ namespace rt {
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 8  // megakernel: waves per SIMD the register allocator must leave room for
 #endif
-#ifndef RT_FAST_TOP
-#define RT_FAST_TOP 192    // fast mode: leading nodes (64 bytes each) kept in LDS per workgroup: 12 KB (kFastTopNodes)
-#endif
+#define RT_FAST_TOP 192    // fast mode: leading nodes (64 bytes each) kept in LDS per workgroup: 12 KB
+static_assert(RT_FAST_TOP == kFastTopNodes, "the builder (rt_fastbvh.cpp) puts exactly the nodes of the LDS copy first");
 // RT_MACRO (rt_internal.h): megakernel tile placement, macro tile = RT_MACRO x RT_MACRO tiles of 16x16 pixels, dealt to the XCDs in turn
 #ifndef RT_EXT_STACK_LDS
 #define RT_EXT_STACK_LDS 8   // traversal kernel of the wavefront pipeline: 2 KB of LDS stack per wavefront
