@@ -789,6 +789,9 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
 #ifndef RT_SOLO_SCALAR
 #define RT_SOLO_SCALAR 1
 #endif
+#ifndef RT_MASK_REST
+#define RT_MASK_REST 1
+#endif
         const uint64_t live = __builtin_amdgcn_ballot_w64(true);
         const bool solo = RT_SOLO_SCALAR && (live & (live - 1u)) == 0u;
         // the address of the item's record (whatever its kind) and of the two runs of 16-byte vectors
@@ -820,6 +823,24 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
         } else {
             const uintptr_t hi = rec & ~(uintptr_t)0xFFFFFFFFu;
             const uintptr_t first = hi | first_lo, rest = hi | rest_lo;
+#if RT_MASK_REST
+            // The last four loads run only in the lanes whose item is not a triangle (a triangle's
+            // lane never looks at a3..a6): every lane of a load instruction is one more access for the
+            // CU's L1 to look up, whatever it returns.
+            const uint64_t wide = __builtin_amdgcn_ballot_w64(type != 0u);
+            uint64_t all_lanes;
+            asm volatile(
+                "global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:16\n\t"
+                "global_load_dwordx4 %2, %8, off offset:32\n\t"
+                "s_mov_b64 %7, exec\n\ts_and_b64 exec, exec, %10\n\t"
+                "global_load_dwordx4 %3, %9, off\n\t"
+                "global_load_dwordx4 %4, %9, off offset:16\n\tglobal_load_dwordx4 %5, %9, off offset:32\n\t"
+                "global_load_dwordx4 %6, %9, off offset:48\n\t"
+                "s_mov_b64 exec, %7"
+                : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), "=&s"(all_lanes)
+                : "v"(first), "v"(rest), "s"(wide)
+                : "memory", "scc");
+#else
             asm volatile(
                 "global_load_dwordx4 %0, %7, off\n\tglobal_load_dwordx4 %1, %7, off offset:16\n\t"
                 "global_load_dwordx4 %2, %7, off offset:32\n\tglobal_load_dwordx4 %3, %8, off\n\t"
@@ -828,6 +849,7 @@ __device__ __forceinline__ void walk_step(const DevScene &sc, v3 O, v3 D, v3 ID,
                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6)
                 : "v"(first), "v"(rest)
                 : "memory");
+#endif
         }
         // either kind returns in order: vector k has arrived when at most 6 - k of its kind are outstanding
         asm volatile("s_waitcnt vmcnt(6) lgkmcnt(6)" : "+v"(a0));
